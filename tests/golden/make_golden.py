@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own CPU path.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+Inputs come from gen_common.py (numpy PCG64 seeds) or from the reference's sample_data
+(K.npy / to_ref_transform.npy / image.png, which are data files); the fixtures store the seeds or
+the small inputs plus the reference's outputs.  No reference source text is stored.
+
+Fixture groups:
+  g1_invdepths     compute_sampling_invdepths                       planesweep_corr.py:524-555
+  g2_sweep_*       PlanesweepCorrelation (grids, masks, corr)       planesweep_corr.py:396-521
+  g3_fusion_*      LearnedFusion                                    learned_fusion.py:24-54
+  g4_warpvar_*     homo_warp + variance                             blocks/utils.py:222-268, mvsnet.py:124-136
+  g5_costreg       CostRegNet                                       mvsnet_components.py:69-123
+  g6_regress       softmax + depth_regression + confidence          mvsnet.py:139-160
+  g7_robustmvd     RobustMVD end-to-end on sample_data (384x576)    robust_mvd.py:57-99
+  g8_mvsnet        MVSNet end-to-end 64x96, D=32, V=2               mvsnet.py:45-168
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _ref_loader import load_reference, REF_ROOT  # noqa: E402
+import gen_common as gc  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+ref = load_reference()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+# ---------------------------------------------------------------------------------------------
+def sample_data_calib():
+    """K (pixel units, 1280x720) and source_to_key transforms of the reference's sample_data."""
+    import os.path as osp
+
+    root = osp.join(REF_ROOT, "sample_data")
+    K = np.load(osp.join(root, "key", "K.npy")).astype(np.float32)
+    key_to_ref = np.load(osp.join(root, "key", "to_ref_transform.npy")).astype(np.float64)
+    ref_to_key = np.linalg.inv(key_to_ref)
+    Ts = []
+    for i in range(6):
+        s2r = np.load(osp.join(root, "source", str(i), "to_ref_transform.npy")).astype(np.float64)
+        Ts.append((s2r @ ref_to_key).astype(np.float32))
+    return K, np.stack(Ts)
+
+
+def g1():
+    out = {}
+    for S in (64, 256):
+        for typ in ("linear_invdepth", "linear_depth"):
+            v = ref.planesweep_corr.compute_sampling_invdepths(0.4, 1000.0, S, typ)
+            out[f"S{S}_{typ}"] = v.numpy()
+    v = ref.planesweep_corr.compute_sampling_invdepths(
+        np.array([0.4, 0.7], np.float32), np.array([1000.0, 50.0], np.float32), 16
+    )
+    out["batched_S16"] = v.numpy()
+    save("g1_invdepths", **out)
+
+
+def run_sweep(feat_key, feat_srcs, K_key, K_srcs, Ts, S=None, min_depth=0.4, max_depth=1000.0, invdepths=None):
+    blk = ref.planesweep_corr.PlanesweepCorrelation()
+    kw = dict(
+        feat_key=t(feat_key),
+        intrinsics_key=t(K_key),
+        feat_sources=[t(f) for f in feat_srcs],
+        source_to_key_transforms=[t(T) for T in Ts],
+        intrinsics_sources=[t(k) for k in K_srcs] if K_srcs is not None else None,
+    )
+    if invdepths is None:
+        kw.update(num_sampling_points=S, min_depth=min_depth, max_depth=max_depth)
+    else:
+        kw.update(sampling_invdepths=t(invdepths))
+    corrs, masks, inv = blk(**kw)
+    us = [sp.us.numpy() for sp in blk.sampling_points]
+    vs = [sp.vs.numpy() for sp in blk.sampling_points]
+    vis = [sp.mask.numpy() for sp in blk.sampling_points]
+    return [c.numpy() for c in corrs], [m.numpy() for m in masks], inv.numpy(), us, vs, vis
+
+
+def g2():
+    K_px, T_sd = sample_data_calib()
+    K_rel = (K_px / np.array([[1280.0] * 3, [720.0] * 3, [1.0] * 3], np.float32))[None]
+
+    def pack(prefix, corrs, masks, us=None, vs=None, vis=None):
+        d = {}
+        for v, (c, m) in enumerate(zip(corrs, masks)):
+            d[f"{prefix}corr{v}"] = c
+            d[f"{prefix}mask{v}"] = np.packbits(m.astype(np.uint8).ravel())
+            if us is not None:
+                d[f"{prefix}us{v}"], d[f"{prefix}vs{v}"] = us[v], vs[v]
+                d[f"{prefix}vis{v}"] = np.packbits(vis[v].astype(np.uint8).ravel())
+        return d
+
+    # (a) toy, sample_data calibration, V=2, inputs stored
+    fk = gc.rng_array(101, (1, 16, 12, 18))
+    fs = [gc.rng_array(102 + i, (1, 16, 12, 18)) for i in range(2)]
+    Ts = [T_sd[0][None], T_sd[1][None]]
+    corrs, masks, inv, us, vs, vis = run_sweep(fk, fs, K_rel, [K_rel, K_rel], Ts, S=8)
+    save("g2_sweep_toy", feat_key=fk, feat_src0=fs[0], feat_src1=fs[1], K_key=K_rel, K_src0=K_rel, K_src1=K_rel,
+         T0=Ts[0], T1=Ts[1], invdepths=inv, **pack("", corrs, masks, us, vs, vis))
+
+    # (b) different source size + different source intrinsics + strong rotation + batch of 2
+    rng = np.random.default_rng(7)
+    fk = gc.rng_array(111, (2, 16, 12, 18))
+    fs = [gc.rng_array(112, (2, 16, 10, 20))]
+    Kk = np.stack([K_rel[0], K_rel[0] * np.array([[1.1], [0.9], [1.0]], np.float32)])
+    Ks = np.stack([K_rel[0] * np.array([[0.8], [1.2], [1.0]], np.float32), K_rel[0]])
+    T = np.stack([gc.synthetic_pose(rng, 0.4, 0.3), gc.synthetic_pose(rng, 0.2, 0.5)])
+    corrs, masks, inv, us, vs, vis = run_sweep(fk, fs, Kk, [Ks], [T], S=8, min_depth=0.3, max_depth=20.0)
+    save("g2_sweep_rot", feat_key=fk, feat_src0=fs[0], K_key=Kk, K_src0=Ks, T0=T, invdepths=inv,
+         **pack("", corrs, masks, us, vs, vis))
+
+    # (c) source camera turned far enough that part of the sweep is behind it (visibility mask,
+    #     non-finite replacement) + explicit per-sample inverse depths incl. linear_depth ordering
+    fk = gc.rng_array(121, (1, 16, 12, 18))
+    fs = [gc.rng_array(122, (1, 16, 12, 18))]
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = gc.rot_xyz(0.1, 0.7, -0.05)
+    T[:3, 3] = [0.2, -0.1, -0.6]
+    inv_in = ref.planesweep_corr.compute_sampling_invdepths(0.4, 5.0, 8, "linear_depth").numpy()
+    corrs, masks, inv, us, vs, vis = run_sweep(fk, fs, K_rel, [K_rel], [T[None]], invdepths=inv_in)
+    save("g2_sweep_behind", feat_key=fk, feat_src0=fs[0], K_key=K_rel, K_src0=K_rel, T0=T[None], invdepths=inv,
+         **pack("", corrs, masks, us, vs, vis))
+
+    # (d) C=256, 24x36, S=64, V=2 (seeds only)
+    fk = gc.rng_array(131, (1, 256, 24, 36))
+    fs = [gc.rng_array(132 + i, (1, 256, 24, 36)) for i in range(2)]
+    Ts = [T_sd[2][None], T_sd[5][None]]
+    corrs, masks, inv, *_ = run_sweep(fk, fs, K_rel, [K_rel, K_rel], Ts, S=64)
+    save("g2_sweep_c256", seed_key=131, seed_src=np.array([132, 133]), shape=np.array([1, 256, 24, 36]), K_key=K_rel,
+         T0=Ts[0], T1=Ts[1], invdepths=inv, **pack("", corrs, masks))
+
+    # (e) BASELINE config 1 at block level: 384x576 -> 48x72 features, C=256, S=64, key + source/0
+    fk = gc.rng_array(141, (1, 256, 48, 72))
+    fs = [gc.rng_array(142, (1, 256, 48, 72))]
+    corrs, masks, inv, *_ = run_sweep(fk, fs, K_rel, [K_rel], [T_sd[0][None]], S=64)
+    save("g2_sweep_cfg1", seed_key=141, seed_src=np.array([142]), shape=np.array([1, 256, 48, 72]), K_key=K_rel,
+         T0=T_sd[0][None], invdepths=inv, **pack("", corrs, masks))
+
+
+def g3():
+    shapes = {"corr_to_view_weight.0.weight": (128, 256, 3, 3), "corr_to_view_weight.0.bias": (128,),
+              "corr_to_view_weight.2.weight": (1, 128, 1, 1), "corr_to_view_weight.2.bias": (1,)}
+    sd = gc.fill_state_dict(shapes, 300)
+    m = ref.learned_fusion.LearnedFusion().eval()
+    m.load_state_dict({k: t(v) for k, v in sd.items()})
+    out = {}
+    for V in (1, 2, 4):
+        rng = np.random.default_rng(310 + V)
+        corrs = [rng.standard_normal((2, 256, 12, 18)).astype(np.float32) for _ in range(V)]
+        masks = [(rng.uniform(size=(2, 256, 12, 18)) > 0.35).astype(np.float32) for _ in range(V)]
+        masks[0][:, :, :3, :4] = 0  # a region where some views are masked
+        if V > 1:
+            for mk in masks:
+                mk[:, 5:9, 6:, 9:] = 0  # a region masked in ALL views -> fused mask 0
+        corrs = [c * mk for c, mk in zip(corrs, masks)]
+        fused, fmask = m([t(c) for c in corrs], [t(mk) for mk in masks])
+        out[f"V{V}_fused"] = fused.numpy()
+        out[f"V{V}_fmask"] = np.packbits(fmask.numpy().astype(np.uint8).ravel())
+    save("g3_fusion", weight_seed=300, **out)
+
+
+def mvs_proj(K, T, key):
+    """Projection matrices exactly as MVSNet.forward builds them (mvsnet.py:76-91)."""
+    Ks = K.copy()
+    Ks[:2] *= 0.25
+    P = T.copy()
+    P[:3, :4] = Ks @ P[:3, :4]
+    return np.linalg.inv(P).astype(np.float32) if key else P.astype(np.float32)
+
+
+def g4():
+    for name, (B, D, V, seed, rot, dmin, dmax) in {
+        "a": (1, 8, 1, 400, 0.05, 0.5, 10.0),
+        "b": (2, 32, 2, 410, 0.05, 0.5, 10.0),
+        "c": (1, 8, 2, 420, 0.6, 0.2, 3.0),  # wide baseline: large parts sample outside / behind the source
+    }.items():
+        h, w, C = 16, 24, 32
+        rng = np.random.default_rng(seed)
+        K = gc.synthetic_intrinsics(h * 4, w * 4)
+        feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for _ in range(V + 1)]
+        depth = np.stack([np.linspace(dmin, dmax, D, dtype=np.float32)] * B)
+        key_inv = np.stack([mvs_proj(K, np.eye(4, dtype=np.float32), True)] * B)
+        srcP = [np.stack([mvs_proj(K, gc.synthetic_pose(rng, rot, 0.15 if rot < 0.1 else 0.6), False) for _ in range(B)])
+                for _ in range(V)]
+        vol_sum = t(feats[0]).unsqueeze(2).repeat(1, 1, D, 1, 1)
+        vol_sq = vol_sum ** 2
+        warped0 = None
+        for v in range(V):
+            wv = ref.blocks_utils.homo_warp(t(feats[v + 1]), t(srcP[v]), t(key_inv), t(depth))
+            if v == 0:
+                warped0 = wv.numpy().copy()
+            vol_sum = vol_sum + wv
+            vol_sq = vol_sq + wv ** 2
+        var = vol_sq.div_(V + 1).sub_(vol_sum.div_(V + 1).pow_(2)).numpy()
+        d = {f"feat{i}": f for i, f in enumerate(feats)}
+        d.update({f"src_proj{v}": p for v, p in enumerate(srcP)})
+        if name == "a":
+            d["warped0"] = warped0
+        save(f"g4_warpvar_{name}", key_proj_inv=key_inv, depth_values=depth, variance=var, **d)
+
+
+COSTREG_SHAPES = None
+
+
+def costreg_shapes():
+    m = ref.mvsnet_components.CostRegNet()
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def g5():
+    sd = gc.fill_state_dict(costreg_shapes(), 500)
+    m = ref.mvsnet_components.CostRegNet().eval()
+    full = {k: t(v) for k, v in sd.items()}
+    for k, v in m.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            full[k] = v
+    m.load_state_dict(full)
+    x = np.abs(gc.rng_array(501, (1, 32, 16, 16, 24), 0.7))
+    y = m(t(x)).numpy()
+    # per-layer outputs of the first two layers, to localise a mismatch
+    c0 = m.conv0(t(x))
+    c1 = m.conv1(c0)
+    save("g5_costreg", weight_seed=500, x_seed=501, out=y, conv0=c0.numpy(), conv1=c1.numpy())
+
+
+def g6():
+    out = {}
+    for name, (B, D, h, w, seed, scale) in {"a": (2, 32, 16, 24, 600, 3.0), "b": (1, 8, 5, 7, 601, 8.0)}.items():
+        cost = gc.rng_array(seed, (B, D, h, w), scale)
+        depth_values = np.stack([np.linspace(0.5, 10.0, D, dtype=np.float32)] * B)
+        p = torch.softmax(t(cost), 1)
+        depth = ref.blocks_utils.depth_regression(p, t(depth_values))
+        sum4 = 4 * torch.nn.functional.avg_pool3d(
+            torch.nn.functional.pad(p.unsqueeze(1), pad=(0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1).squeeze(1)
+        idx = ref.blocks_utils.depth_regression(p, torch.arange(D, dtype=p.dtype)).long()
+        conf = torch.gather(sum4, 1, idx.unsqueeze(1)).squeeze(1)
+        out.update({f"{name}_seed": seed, f"{name}_scale": scale, f"{name}_shape": np.array([B, D, h, w]),
+                    f"{name}_depth": depth.numpy(), f"{name}_conf": conf.numpy(), f"{name}_idx": idx.numpy()})
+    save("g6_regress", **out)
+
+
+def g7():
+    from PIL import Image
+    import os.path as osp
+
+    H, W = 384, 576
+    root = osp.join(REF_ROOT, "sample_data")
+    K_px, T_sd = sample_data_calib()
+    imgs = []
+    for p in (osp.join(root, "key", "image.png"), osp.join(root, "source", "0", "image.png")):
+        im = Image.open(p).convert("RGB").resize((W, H), Image.BILINEAR)
+        imgs.append(np.asarray(im, dtype=np.uint8).transpose(2, 0, 1))
+    K = K_px * np.array([[W / 1280.0] * 3, [H / 720.0] * 3, [1.0] * 3], np.float32)
+    model = ref.robust_mvd.RobustMVD().eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.robustmvd_weights(shapes, 700)
+    model.load_state_dict({k: t(v) for k, v in sd.items()})
+    ref.helpers.add_run_function(model)
+    sample = dict(images=[imgs[0].astype(np.float32), imgs[1].astype(np.float32)],
+                  intrinsics=[K.copy(), K.copy()],
+                  poses=[np.eye(4, dtype=np.float32), T_sd[0]], keyview_idx=0)
+    pred, aux = model.run(**sample)
+    # intermediate: fused correlation volume (input of the 2-D cost-volume encoder)
+    b_images, b_key, b_poses, b_intr, _ = ref.helpers.add_batch_dim(
+        sample["images"], 0, sample["poses"], sample["intrinsics"])
+    inp = model.input_adapter(images=b_images, keyview_idx=b_key, poses=b_poses, intrinsics=b_intr)
+    enc_key = model.encoder(inp["images"][0])[1]
+    enc_src = model.encoder(inp["images"][1])[1]
+    corrs, masks, _ = model.corr_block(feat_key=enc_key, intrinsics_key=inp["intrinsics"][0], feat_sources=[enc_src],
+                                       source_to_key_transforms=[inp["poses"][1]], intrinsics_sources=[inp["intrinsics"][1]],
+                                       num_sampling_points=256, min_depth=0.4, max_depth=1000.0)
+    save("g7_robustmvd", image_key=imgs[0], image_src0=imgs[1], K=K, T0=T_sd[0], weight_seed=700,
+         depth=pred["depth"], depth_uncertainty=pred["depth_uncertainty"],
+         invdepth=aux["invdepth"], invdepth_log_b=aux["invdepth_log_b"],
+         invdepths_all_0=aux["invdepths_all"][0], invdepths_all_3=aux["invdepths_all"][3],
+         corr0_sub=corrs[0].numpy()[:, ::4, ::2, ::2], mask0=np.packbits(masks[0].numpy().astype(np.uint8).ravel()),
+         enc_key_sub=enc_key.numpy()[:, ::16, ::4, ::4])
+
+    # the same weights with 2 source views at 128x192 exercise the learned fusion inside the model
+    H2, W2 = 128, 192
+    rng = np.random.default_rng(710)
+    images = [rng.uniform(0, 255, (3, H2, W2)).astype(np.float32) for _ in range(3)]
+    K2 = gc.synthetic_intrinsics(H2, W2)
+    poses = [gc.synthetic_pose(rng), np.eye(4, dtype=np.float32), gc.synthetic_pose(rng)]
+    pred, aux = model.run(images=images, intrinsics=[K2, K2, K2], poses=poses, keyview_idx=1)
+    save("g7_robustmvd_v2", seed=710, weight_seed=700, depth=pred["depth"], invdepth=aux["invdepth"],
+         invdepth_log_b=aux["invdepth_log_b"], depth_uncertainty=pred["depth_uncertainty"])
+
+
+def g8():
+    H, W, D, V = 64, 96, 32, 2
+    model = ref.mvsnet.MVSNet(num_sampling_steps=D).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.fill_state_dict(shapes, 800)
+    full = {k: t(v) for k, v in sd.items()}
+    for k, v in model.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            full[k] = v
+    model.load_state_dict(full)
+    s = gc.synthetic_sample(801, H, W, V)
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
+    images = [t(((im / 255.0 - mean) / std).astype(np.float32)[None]) for im in s["images"]]
+    poses = [t(p[None].copy()) for p in s["poses"]]
+    intr = [t(k[None].copy()) for k in s["intrinsics"]]
+    pred, _ = model(images=images, poses=poses, intrinsics=intr, keyview_idx=torch.tensor([0]),
+                    depth_range=[torch.tensor([0.5]), torch.tensor([10.0])])
+    save("g8_mvsnet", sample_seed=801, weight_seed=800, shape=np.array([H, W, D, V]),
+         depth=pred["depth"].numpy(), depth_uncertainty=pred["depth_uncertainty"].numpy())
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    for g in which:
+        globals()[g]()

@@ -1,0 +1,145 @@
+"""The CPU oracle against the golden vectors made from the reference's own CPU path
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+import gen_common as gc
+from conftest import load_golden, unpack_mask
+from oracle import mvd_oracle as O
+
+ATOL = RTOL = 1e-4  # SURVEY.md 8(c) block-level tolerance, fp32
+
+
+def test_g1_invdepths():
+    g = load_golden("g1_invdepths")
+    for S in (64, 256):
+        for typ in ("linear_invdepth", "linear_depth"):
+            got = O.compute_sampling_invdepths(0.4, 1000.0, S, typ)
+            np.testing.assert_allclose(got, g[f"S{S}_{typ}"], rtol=1e-6, atol=1e-9)
+    got = O.compute_sampling_invdepths(np.array([0.4, 0.7], np.float32), np.array([1000.0, 50.0], np.float32), 16)
+    np.testing.assert_allclose(got, g["batched_S16"], rtol=1e-6, atol=1e-9)
+
+
+def _sweep_inputs(g, V):
+    if "feat_key" in g.files:
+        fk = g["feat_key"]
+        fs = [g[f"feat_src{v}"] for v in range(V)]
+    else:
+        shape = tuple(g["shape"])
+        fk = gc.rng_array(int(g["seed_key"]), shape)
+        fs = [gc.rng_array(int(s), shape) for s in g["seed_src"]]
+    Ks = [g[f"K_src{v}"] if f"K_src{v}" in g.files else g["K_key"] for v in range(V)]
+    Ts = [g[f"T{v}"] for v in range(V)]
+    return fk, fs, g["K_key"], Ks, Ts
+
+
+def check_sweep_outputs(g, V, corrs, masks, atol=ATOL, rtol=RTOL):
+    for v in range(V):
+        ref_corr = g[f"corr{v}"]
+        ref_mask = unpack_mask(g[f"mask{v}"], ref_corr.shape)
+        mism = masks[v] != ref_mask
+        # a sample within 1e-4 px of the border may flip its mask; none expected here
+        assert mism.mean() <= 1e-4, f"view {v}: {mism.sum()} mask mismatches"
+        ok = ~mism
+        np.testing.assert_allclose(corrs[v][ok], ref_corr[ok], atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("name,V", [("g2_sweep_toy", 2), ("g2_sweep_rot", 1), ("g2_sweep_behind", 1),
+                                    ("g2_sweep_c256", 2), ("g2_sweep_cfg1", 1)])
+def test_g2_sweep(name, V):
+    g = load_golden(name)
+    fk, fs, Kk, Ks, Ts = _sweep_inputs(g, V)
+    inv = g["invdepths"][:, :, 0, 0]
+    h, w = fk.shape[-2:]
+    if "us0" in g.files:  # grids + visibility (rows A2, A3)
+        for v in range(V):
+            co = O.epipolar_coeffs(Kk, Ks[v], Ts[v], h, w, fs[v].shape[2], fs[v].shape[3])
+            us, vs, vis = O.sweep_grids(co, np.broadcast_to(inv, (fk.shape[0], inv.shape[1])))
+            np.testing.assert_allclose(us, g[f"us{v}"], rtol=2e-5, atol=1e-4)
+            np.testing.assert_allclose(vs, g[f"vs{v}"], rtol=2e-5, atol=1e-4)
+            assert (vis == unpack_mask(g[f"vis{v}"], vis.shape).astype(bool)).all()
+    corrs, masks, inv_out = O.planesweep_correlation(fk, Kk, fs, Ts, Ks, sampling_invdepths=inv)
+    assert inv_out.shape == g["invdepths"].shape
+    check_sweep_outputs(g, V, corrs, masks)
+
+
+def fusion_weights():
+    shapes = {"corr_to_view_weight.0.weight": (128, 256, 3, 3), "corr_to_view_weight.0.bias": (128,),
+              "corr_to_view_weight.2.weight": (1, 128, 1, 1), "corr_to_view_weight.2.bias": (1,)}
+    return gc.fill_state_dict(shapes, 300)
+
+
+def fusion_inputs(V):
+    rng = np.random.default_rng(310 + V)
+    corrs = [rng.standard_normal((2, 256, 12, 18)).astype(np.float32) for _ in range(V)]
+    masks = [(rng.uniform(size=(2, 256, 12, 18)) > 0.35).astype(np.float32) for _ in range(V)]
+    masks[0][:, :, :3, :4] = 0
+    if V > 1:
+        for mk in masks:
+            mk[:, 5:9, 6:, 9:] = 0
+    corrs = [c * mk for c, mk in zip(corrs, masks)]
+    return corrs, masks
+
+
+@pytest.mark.parametrize("V", [1, 2, 4])
+def test_g3_fusion(V):
+    g = load_golden("g3_fusion")
+    sd = fusion_weights()
+    corrs, masks = fusion_inputs(V)
+    scores = [O.fusion_scores(c, sd["corr_to_view_weight.0.weight"], sd["corr_to_view_weight.0.bias"],
+                              sd["corr_to_view_weight.2.weight"], sd["corr_to_view_weight.2.bias"]) for c in corrs]
+    fused, fmask = O.fuse_views(corrs, masks, scores)
+    ref_fused = g[f"V{V}_fused"]
+    assert (fmask == unpack_mask(g[f"V{V}_fmask"], ref_fused.shape)).all()
+    np.testing.assert_allclose(fused, ref_fused, atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("name,V", [("g4_warpvar_a", 1), ("g4_warpvar_b", 2), ("g4_warpvar_c", 2)])
+def test_g4_warp_variance(name, V):
+    g = load_golden(name)
+    feats = [g[f"feat{i}"] for i in range(V + 1)]
+    projs = [g[f"src_proj{v}"] for v in range(V)]
+    if "warped0" in g.files:
+        w0 = O.homo_warp(feats[1], projs[0], g["key_proj_inv"], g["depth_values"])
+        np.testing.assert_allclose(w0, g["warped0"], atol=ATOL, rtol=RTOL)
+    var = O.warp_variance(feats[0], feats[1:], projs, g["key_proj_inv"], g["depth_values"])
+    np.testing.assert_allclose(var, g["variance"], atol=ATOL, rtol=RTOL)
+
+
+def costreg_shapes():
+    s = {}
+    for name, (ci, co) in dict(conv0=(32, 8), conv1=(8, 16), conv2=(16, 16), conv3=(16, 32), conv4=(32, 32),
+                               conv5=(32, 64), conv6=(64, 64)).items():
+        s[f"{name}.conv.weight"] = (co, ci, 3, 3, 3)
+        for p in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{name}.bn.{p}"] = (co,)
+    for name, (ci, co) in dict(conv7=(64, 32), conv9=(32, 16), conv11=(16, 8)).items():
+        s[f"{name}.0.weight"] = (ci, co, 3, 3, 3)
+        for p in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{name}.1.{p}"] = (co,)
+    s["prob.weight"] = (1, 8, 3, 3, 3)
+    s["prob.bias"] = (1,)
+    return s
+
+
+def test_g5_costreg():
+    g = load_golden("g5_costreg")
+    sd = gc.fill_state_dict(costreg_shapes(), int(g["weight_seed"]))
+    x = np.abs(gc.rng_array(int(g["x_seed"]), (1, 32, 16, 16, 24), 0.7))
+    out, mids = O.cost_reg_net(x, sd, return_all=True)
+    np.testing.assert_allclose(mids["conv0"], g["conv0"], atol=ATOL, rtol=RTOL)
+    np.testing.assert_allclose(mids["conv1"], g["conv1"], atol=ATOL, rtol=RTOL)
+    np.testing.assert_allclose(out, g["out"], atol=2e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_g6_regress(name):
+    g = load_golden("g6_regress")
+    B, D, h, w = g[f"{name}_shape"]
+    cost = gc.rng_array(int(g[f"{name}_seed"]), (B, D, h, w), float(g[f"{name}_scale"]))
+    dv = np.stack([np.linspace(0.5, 10.0, D, dtype=np.float32)] * B)
+    depth, conf, idx = O.softmax_regress(cost, dv)
+    np.testing.assert_allclose(depth, g[f"{name}_depth"], atol=1e-5, rtol=1e-5)
+    same = idx == g[f"{name}_idx"]
+    assert same.mean() > 0.999  # an expected index within float rounding of an integer may truncate differently
+    np.testing.assert_allclose(conf[same], g[f"{name}_conf"][same], atol=1e-5, rtol=1e-5)
