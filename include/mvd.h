@@ -1,0 +1,148 @@
+/*
+ * mvd.h — C ABI of libmvd_hip.so: the MI355X (gfx950) plane-sweep cost-volume engine that sits
+ * behind the reference's model protocol (rmvd.create_model("robust_mvd") / "mvsnet_train").
+ *
+ * Every entry point replaces a composition of stock torch ops in the reference (the reference has
+ * no native code); the file:line each one replaces is cited per function, relative to
+ * the reference repository root.
+ *
+ * Conventions
+ *   - all tensors fp32, contiguous, resident in device (HBM) memory; `const float* const*` arguments
+ *     are HOST arrays of V device pointers (one per source view), V <= MVD_MAX_VIEWS;
+ *   - calibration (intrinsics, poses, projection matrices, depth samples) is passed as DEVICE
+ *     pointers too: the kernels derive their per-view coefficients themselves, so a call never
+ *     synchronises with the host and can be captured into a hipGraph;
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library allocates nothing and
+ *     keeps no pointer after the call returns; kernels are enqueued on `stream` (a hipStream_t;
+ *     NULL = the default stream) of the CURRENT device and the call returns without waiting;
+ *   - re-entrant, no global mutable state except a thread-local error string;
+ *   - return value: 0 = MVD_OK, otherwise an mvd_status; mvd_last_error() describes the failure.
+ */
+#ifndef MVD_H_
+#define MVD_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVD_VERSION 100 /* 0.1.0 */
+#define MVD_MAX_VIEWS 16
+
+typedef void* mvd_stream_t; /* hipStream_t */
+
+typedef enum {
+    MVD_OK = 0,
+    MVD_ERR_INVALID_ARG = 1, /* NULL pointer, non-positive dimension, unsupported channel count ... */
+    MVD_ERR_WORKSPACE = 2,   /* workspace NULL or smaller than the *_workspace_bytes() answer */
+    MVD_ERR_LAUNCH = 3,      /* HIP reported an error when enqueueing (message has hipGetErrorString) */
+    MVD_ERR_NO_DEVICE = 4    /* no gfx950 device visible */
+} mvd_status;
+
+/* layouts of a 5-D cost volume */
+#define MVD_LAYOUT_NCDHW 0 /* (B, C, D, h, w): what the reference's homo_warp / CostRegNet use */
+#define MVD_LAYOUT_NDHWC 1 /* (B, D, h, w, C): channel-last, what the engine uses between its own kernels */
+
+int mvd_version(void);
+/* thread-local; valid until the next failing call on this thread */
+const char* mvd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Path A (robust_mvd): inverse-depth plane sweep with dot-product correlation
+ * ---------------------------------------------------------------------------------------------- */
+
+/* K1 — replaces PlanesweepCorrelation.forward for ALL source views in one call:
+ *   EpipolarCoeffs.from_calib            rmvd/models/blocks/planesweep_corr.py:228-300
+ *   us_from_ds / vs_from_ds (+non-finite replacement)                         :333-349
+ *   visibility mask of get_plane_sweep_sampling_points                        :489-512
+ *   TorchCorr.forward (all-pairs matmul, /sqrt(C), grid_sample lookup, masks) :152-195 with warp() :49-104
+ *   correlate() loop over views                                               :514-521
+ *
+ *   feat_key   (N,C,h,w)              key-view features
+ *   feat_src   V x (N,C,hs,ws)        source-view features
+ *   K_key      (N,3,3)                relative intrinsics of the key view (fx,fy,cx,cy in [0,1])
+ *   K_src      V x (N,3,3)            relative intrinsics of each source view
+ *   T_src2key  V x (N,4,4)            source_to_key_transform (p_src = T p_key)
+ *   invdepths  (N,S) if invdepth_batched else (1,S)   sampling inverse depths
+ *   corr_out   V x (N,S,h,w)          mask * (1/sqrt(C)) * sum_c f_key * bilinear(f_src)
+ *   mask_out   V x (N,S,h,w)          1.0 where all bilinear taps are in bounds (weight sum >= 0.9999)
+ *                                     and the plane is in front of both cameras, else 0.0
+ * C must be a multiple of 64 (256 in robust_mvd). */
+size_t mvd_sweep_corr_workspace_bytes(int N, int C, int h, int w, int hs, int ws, int V);
+int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
+                       const float* const* K_src, const float* const* T_src2key, const float* invdepths,
+                       int invdepth_batched, int N, int C, int h, int w, int hs, int ws, int S, int V,
+                       float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
+                       mvd_stream_t stream);
+
+/* K2 — replaces the view-weighting arithmetic of LearnedFusion.forward
+ *   rmvd/models/blocks/learned_fusion.py:32-48 (softmax over views + 1e-9, mask-weighted mean, fused mask).
+ * The per-view score maps (conv3x3+ReLU+conv1x1, :13-17,:28-30) are 2-D convolutions that stay on
+ * MIOpen and are passed in.  V == 1 is the caller's pass-through (:50-52) and is rejected here.
+ *   corr, mask  V x (N,S,h,w);  score  V x (N,1,h,w);  fused, fused_mask  (N,S,h,w) */
+int mvd_fuse_views_f32(const float* const* corr, const float* const* mask, const float* const* score, int N, int S,
+                       int h, int w, int V, float* fused, float* fused_mask, mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Path B (mvsnet): fronto-parallel homography warp, variance aggregation, 3-D regulariser, soft argmin
+ * ---------------------------------------------------------------------------------------------- */
+
+/* K3 — replaces the cost-volume construction of MVSNet.forward:
+ *   homo_warp for every source view                rmvd/models/blocks/utils.py:222-268
+ *   key volume repeat + sum / sum-of-squares loop  rmvd/models/mvsnet.py:124-133
+ *   variance                                       rmvd/models/mvsnet.py:135
+ *
+ *   key_feat      (B,C,h,w)
+ *   src_feat      V x (B,C,h,w)
+ *   src_proj      V x (B,4,4)      source projection matrices (mvsnet.py:76-88)
+ *   key_proj_inv  (B,4,4)          inverse key projection (mvsnet.py:85-86)
+ *   depth_values  (B,D)
+ *   var_out       (B,C,D,h,w) for MVD_LAYOUT_NCDHW or (B,D,h,w,C) for MVD_LAYOUT_NDHWC
+ * C must be a multiple of 4 and <= 64 (32 in MVSNet).  Algorithmic HBM bytes: 4*((V+1)*C*h*w + C*D*h*w)*B. */
+size_t mvd_warp_variance_workspace_bytes(int B, int C, int h, int w, int V);
+int mvd_warp_variance_f32(const float* key_feat, const float* const* src_feat, const float* const* src_proj,
+                          const float* key_proj_inv, const float* depth_values, int B, int C, int D, int h, int w,
+                          int V, float* var_out, int out_layout, void* workspace, size_t workspace_bytes,
+                          mvd_stream_t stream);
+
+/* homo_warp alone (one view, no aggregation): rmvd/models/blocks/utils.py:222-268 -> (B,C,D,h,w). */
+int mvd_homo_warp_f32(const float* src_feat, const float* src_proj, const float* key_proj_inv,
+                      const float* depth_values, int B, int C, int D, int h, int w, float* warped_out,
+                      void* workspace, size_t workspace_bytes, mvd_stream_t stream);
+
+/* K4 — one layer of CostRegNet (rmvd/models/blocks/mvsnet_components.py:69-123) as an implicit GEMM
+ * on the fp32 matrix cores: 3x3x3 Conv3d (stride 1 or 2, padding 1; ConvBnReLU3D :25-41) or
+ * ConvTranspose3d (stride 2, padding 1, output_padding 1; :84-109), followed by a per-channel affine
+ * (eval-mode BatchNorm folded to scale/shift, or scale=1 / shift=bias for `prob`), optional ReLU and
+ * optional skip addition AFTER the ReLU (the `conv4 + conv7(x)` form of :116-121).
+ * Activations are channel-last (B,D,h,w,C).  Weights must first be packed with mvd_pack_conv3d_weights_f32. */
+#define MVD_CONV3D_STRIDE1 0
+#define MVD_CONV3D_STRIDE2 1
+#define MVD_DECONV3D_STRIDE2 2
+size_t mvd_conv3d_packed_weight_floats(int Cin, int Cout);
+/* w: Conv3d layout (Cout,Cin,3,3,3), or ConvTranspose3d layout (Cin,Cout,3,3,3) when mode == MVD_DECONV3D_STRIDE2 */
+int mvd_pack_conv3d_weights_f32(const float* w, int Cin, int Cout, int mode, float* packed, mvd_stream_t stream);
+/* x (B,Di,hi,wi,Cin) -> y (B,Do,ho,wo,Cout); Do = Di (stride 1), Di/2 (stride 2; Di,hi,wi even), 2*Di (deconv).
+ * scale, shift (Cout); skip NULL or (B,Do,ho,wo,Cout).  Cin in {8,16,32,64}; Cout in {1,8,16,32,64}. */
+int mvd_conv3d_bn_relu_f32(const float* x, const float* packed_w, const float* scale, const float* shift,
+                           const float* skip, float* y, int B, int Di, int hi, int wi, int Cin, int Cout, int mode,
+                           int relu, mvd_stream_t stream);
+
+/* K5 — replaces F.softmax + depth_regression + the 4-bin confidence of MVSNet.forward
+ *   rmvd/models/mvsnet.py:139-160, rmvd/models/blocks/utils.py:271-274.
+ *   cost (B,D,h,w) raw regulariser output; depth_values (B,D);
+ *   depth_out (B,h,w) = sum_d softmax(cost)_d * depth_d
+ *   conf_out  (B,h,w) = sum_{j=idx-1..idx+2, 0<=j<D} softmax(cost)_j, idx = trunc(sum_d p_d * d)
+ * (the reference returns uncertainty = 1 - conf). conf_out may be NULL. */
+int mvd_softmax_regress_f32(const float* cost, const float* depth_values, int B, int D, int h, int w,
+                            float* depth_out, float* conf_out, mvd_stream_t stream);
+
+/* layout helpers used at the operator-level boundary (reference tensors are NCHW / NCDHW) */
+int mvd_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);
+int mvd_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVD_H_ */

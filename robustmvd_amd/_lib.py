@@ -1,0 +1,98 @@
+"""ctypes binding of libmvd_hip.so (include/mvd.h).  PyTorch tensors are only used for device
+memory and the current stream; the library sees raw device pointers.
+
+There is NO CPU fallback: if the library is missing or cannot be loaded the import of any op raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvd_hip.so")
+
+MVD_MAX_VIEWS = 16
+LAYOUT_NCDHW = 0
+LAYOUT_NDHWC = 1
+CONV3D_STRIDE1 = 0
+CONV3D_STRIDE2 = 1
+DECONV3D_STRIDE2 = 2
+
+_c_float_p = ctypes.c_void_p
+_pp = ctypes.POINTER(ctypes.c_void_p)
+_i = ctypes.c_int
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mvd.h one to one
+SIGNATURES = {
+    "mvd_version": (_i, []),
+    "mvd_last_error": (ctypes.c_char_p, []),
+    "mvd_sweep_corr_workspace_bytes": (_sz, [_i] * 7),
+    "mvd_sweep_corr_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i] + [_i] * 8
+                           + [_pp, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_fuse_views_f32": (_i, [_pp, _pp, _pp, _i, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "mvd_warp_variance_workspace_bytes": (_sz, [_i] * 5),
+    "mvd_warp_variance_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p] + [_i] * 6
+                              + [_c_float_p, _i, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_homo_warp_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [_c_float_p, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_conv3d_packed_weight_floats": (_sz, [_i, _i]),
+    "mvd_pack_conv3d_weights_f32": (_i, [_c_float_p, _i, _i, _i, _c_float_p, ctypes.c_void_p]),
+    "mvd_conv3d_bn_relu_f32": (_i, [_c_float_p] * 6 + [_i] * 8 + [ctypes.c_void_p]),
+    "mvd_softmax_regress_f32": (_i, [_c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "mvd_nchw_to_nhwc_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),
+    "mvd_nhwc_to_nchw_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libmvd_hip.so (once).  Raises RuntimeError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C robustmvd_amd/csrc`. There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mvd_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (status {rc}): {msg}")
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return ctypes.cast(arr, _pp), arr  # keep `arr` alive in the caller
+
+
+def as_f32(t, name, shape=None, device=None):
+    """Validates a tensor argument at the boundary (reference: asserts, planesweep_corr.py:444,473-483)."""
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: tensor is on {t.device}; the HIP engine needs a cuda (ROCm) device tensor")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name}: on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t.contiguous()

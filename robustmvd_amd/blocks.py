@@ -1,0 +1,337 @@
+"""Operator-level modules of the plane-sweep path with the reference's names, signatures and
+state-dict keys; their forward passes run on the HIP engine (ops.py).
+
+  PlanesweepCorrelation   rmvd/models/blocks/planesweep_corr.py:371-521   -> K1 mvd_sweep_corr_f32
+  LearnedFusion           rmvd/models/blocks/learned_fusion.py:6-54       -> MIOpen score convs + K2 mvd_fuse_views_f32
+  homo_warp               rmvd/models/blocks/utils.py:222-268             -> mvd_homo_warp_f32
+  CostRegNet              rmvd/models/blocks/mvsnet_components.py:69-123  -> K4 mvd_conv3d_bn_relu_f32 x 11
+  depth_regression        rmvd/models/blocks/utils.py:271-274             (plain expectation; the fused K5 is ops.softmax_regress)
+
+The 2-D CNNs next to the path (DispNet encoder/decoder, MVSNet FeatureNet) are ordinary torch modules
+that run on MIOpen; they are not part of the hand-written path.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .utils import to_torch
+
+homo_warp = ops.homo_warp
+
+
+def compute_sampling_invdepths(min_depth, max_depth, num_samples, sampling_type="linear_invdepth"):
+    """planesweep_corr.py:524-555. Scalars or per-sample arrays -> (1 or N, num_samples), far to near."""
+    def col(v):
+        if isinstance(v, (float, int, np.floating)):
+            v = torch.tensor([float(v)])
+        return to_torch(v).float()[..., None]
+
+    lo, hi = col(min_depth), col(max_depth)
+    steps = torch.arange(0, num_samples, dtype=lo.dtype, device=lo.device)[None]
+    if sampling_type == "linear_invdepth":
+        return 1 / hi + steps * (1 / lo - 1 / hi) / (num_samples - 1)
+    if sampling_type == "linear_depth":
+        return (1 / (lo + steps * (hi - lo) / (num_samples - 1))).flip(1)
+    raise ValueError(f"sampling_type {sampling_type!r}")
+
+
+class PlanesweepCorrelation(nn.Module):
+    """Same call signature and return value as the reference block; no parameters.
+    Stateless across calls (the reference keeps per-call state on self and is not re-entrant)."""
+
+    def __init__(self, warp_only=False, normalize="dim"):
+        super().__init__()
+        if warp_only or normalize != "dim":
+            raise NotImplementedError("only the configuration robust_mvd uses (TorchCorr, normalize='dim') is built")
+
+    @torch.no_grad()
+    def forward(self, feat_key, intrinsics_key, feat_sources, source_to_key_transforms, intrinsics_sources=None,
+                num_sampling_points=None, min_depth=None, max_depth=None, sampling_invdepths=None,
+                sampling_type="linear_invdepth"):
+        if intrinsics_sources is None:
+            intrinsics_sources = [intrinsics_key] * len(feat_sources)
+        if not (len(feat_sources) == len(source_to_key_transforms) == len(intrinsics_sources)):
+            raise ValueError("feat_sources, source_to_key_transforms and intrinsics_sources differ in length")
+        if min_depth is not None and max_depth is not None:
+            if sampling_invdepths is not None or num_sampling_points is None or sampling_type is None:
+                raise ValueError("give either (num_sampling_points, min_depth, max_depth) or sampling_invdepths")
+            sampling_invdepths = compute_sampling_invdepths(min_depth, max_depth, num_sampling_points, sampling_type)
+        elif num_sampling_points is not None or min_depth is not None or max_depth is not None or sampling_invdepths is None:
+            raise ValueError("give either (num_sampling_points, min_depth, max_depth) or sampling_invdepths")
+        inv = sampling_invdepths.to(feat_key.device)
+        if inv.dim() < 2:
+            raise ValueError("sampling_invdepths needs at least 2 dims (N, S)")
+        if inv.dim() > 2:
+            if any(s != 1 for s in inv.shape[2:]):
+                raise NotImplementedError("per-pixel sampling_invdepths (N,S,H,W) are not supported by the engine")
+            inv = inv.reshape(inv.shape[0], inv.shape[1])
+        # sources may differ in size: one launch per group of equal (hs, ws)
+        corrs = [None] * len(feat_sources)
+        masks = [None] * len(feat_sources)
+        groups = {}
+        for i, f in enumerate(feat_sources):
+            groups.setdefault(tuple(f.shape[-2:]), []).append(i)
+        for idxs in groups.values():
+            c, m = ops.sweep_corr(feat_key, [feat_sources[i] for i in idxs], intrinsics_key,
+                                  [intrinsics_sources[i] for i in idxs], [source_to_key_transforms[i] for i in idxs], inv)
+            for i, ci, mi in zip(idxs, c, m):
+                corrs[i], masks[i] = ci, mi
+        return corrs, masks, inv[:, :, None, None]
+
+
+class LearnedFusion(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.corr_to_view_weight = nn.Sequential(
+            nn.Conv2d(256, 128, kernel_size=3, stride=1, padding=1, bias=True),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(128, 1, kernel_size=1, stride=1, padding=0, bias=True),
+        )
+
+    def forward(self, corrs, masks):
+        if len(corrs) == 1:
+            return corrs[0], masks[0]
+        n = corrs[0].shape[0]
+        scores = self.corr_to_view_weight(torch.cat(list(corrs), 0))  # one batched MIOpen call for all views
+        return ops.fuse_views(corrs, masks, list(torch.split(scores, n, 0)))
+
+
+def depth_regression(p, depth_values):
+    return torch.sum(p * depth_values.view(*depth_values.shape, 1, 1), 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# MVSNet components
+# ------------------------------------------------------------------------------------------------
+class ConvBnReLU(nn.Module):
+    def __init__(self, cin, cout, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+class FeatureNet(nn.Module):
+    """2-D feature pyramid of MVSNet (mvsnet_components.py:44-66); runs on MIOpen."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        spec = [(3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1), (16, 16, 3, 1, 1),
+                (16, 32, 5, 2, 2), (32, 32, 3, 1, 1)]
+        for i, s in enumerate(spec):
+            setattr(self, f"conv{i}", ConvBnReLU(*s))
+        self.feature = nn.Conv2d(32, 32, 3, 1, 1)
+
+    def forward(self, x):
+        for i in range(7):
+            x = getattr(self, f"conv{i}")(x)
+        return self.feature(x)
+
+
+class ConvBnReLU3D(nn.Module):
+    def __init__(self, cin, cout, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm3d(cout)
+
+
+def _deconv_block(cin, cout):
+    return nn.Sequential(nn.ConvTranspose3d(cin, cout, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                         nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+
+class CostRegNet(nn.Module):
+    """3-D U-Net regulariser.  Parameters live in ordinary nn.Conv3d / nn.BatchNorm3d modules (so the
+    reference's checkpoints load); forward folds BN (eval mode) and runs 11 fused HIP layers on
+    channel-last activations."""
+
+    LAYERS = [("conv0", 32, 8, 1), ("conv1", 8, 16, 2), ("conv2", 16, 16, 1), ("conv3", 16, 32, 2), ("conv4", 32, 32, 1),
+              ("conv5", 32, 64, 2), ("conv6", 64, 64, 1)]
+    UPS = [("conv7", 64, 32), ("conv9", 32, 16), ("conv11", 16, 8)]
+
+    def __init__(self):
+        super().__init__()
+        for name, cin, cout, stride in self.LAYERS:
+            setattr(self, name, ConvBnReLU3D(cin, cout, stride=stride))
+        for name, cin, cout in self.UPS:
+            setattr(self, name, _deconv_block(cin, cout))
+        self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
+        self._packed = None
+        self._packed_key = None
+
+    @staticmethod
+    def _fold(bn):
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
+
+    def _prepare(self):
+        """Packs weights into MFMA fragment order and folds BN; cached until a parameter changes."""
+        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        if self.training:
+            raise RuntimeError("CostRegNet HIP path folds BatchNorm running statistics: call .eval() first")
+        pk = {}
+        for name, cin, cout, stride in self.LAYERS:
+            m = getattr(self, name)
+            mode = L.CONV3D_STRIDE1 if stride == 1 else L.CONV3D_STRIDE2
+            w, _, _ = ops.pack_conv3d_weights(m.conv.weight.detach(), mode)
+            pk[name] = (w, cin, cout, *self._fold(m.bn), mode)
+        for name, cin, cout in self.UPS:
+            m = getattr(self, name)
+            w, _, _ = ops.pack_conv3d_weights(m[0].weight.detach(), L.DECONV3D_STRIDE2)
+            pk[name] = (w, cin, cout, *self._fold(m[1]), L.DECONV3D_STRIDE2)
+        w, _, _ = ops.pack_conv3d_weights(self.prob.weight.detach(), L.CONV3D_STRIDE1)
+        pk["prob"] = (w, 8, 1, torch.ones(1, device=w.device), self.prob.bias.detach().contiguous(), L.CONV3D_STRIDE1)
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    @torch.no_grad()
+    def forward_channels_last(self, x):
+        """x (B,D,h,w,32) -> cost (B,D,h,w) (the single output channel squeezed)."""
+        if x.shape[1] % 8 or x.shape[2] % 8 or x.shape[3] % 8:
+            raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {tuple(x.shape[1:4])}")
+        pk = self._prepare()
+
+        def layer(name, t, relu=True, skip=None):
+            w, cin, cout, scale, shift, mode = pk[name]
+            return ops.conv3d_bn_relu(t, w, cin, cout, scale, shift, mode, relu=relu, skip=skip)
+
+        conv0 = layer("conv0", x)
+        conv2 = layer("conv2", layer("conv1", conv0))
+        conv4 = layer("conv4", layer("conv3", conv2))
+        y = layer("conv6", layer("conv5", conv4))
+        y = layer("conv7", y, skip=conv4)
+        del conv4
+        y = layer("conv9", y, skip=conv2)
+        del conv2
+        y = layer("conv11", y, skip=conv0)
+        del conv0
+        return layer("prob", y, relu=False).squeeze(-1)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """Reference layout: (B,32,D,h,w) -> (B,1,D,h,w)."""
+        return self.forward_channels_last(ops.to_channels_last_3d(x)).unsqueeze(1)
+
+
+# ------------------------------------------------------------------------------------------------
+# DispNet 2-D CNN around the Path-A sweep (plain torch; MIOpen)
+# ------------------------------------------------------------------------------------------------
+def conv(cin, cout, kernel_size=3, stride=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=True),
+                         nn.LeakyReLU(0.2, inplace=True))
+
+
+class ReLUAndSigmoid(nn.Module):
+    """Channel 0: ReLU (inverse depth); other channels: range-scaled sigmoid (log scale), blocks/utils.py:30-41."""
+
+    def __init__(self, inplace=False, min=0.0, max=1.0):
+        super().__init__()
+        self.min, self.max, self.range = min, max, max - min
+
+    def forward(self, x):
+        return torch.cat([F.relu(x[:, :1]), torch.sigmoid(x[:, 1:] * (4 / self.range)) * self.range + self.min], 1)
+
+
+class DispnetEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = conv(3, 64, kernel_size=7, stride=2)
+        self.conv2 = conv(64, 128, kernel_size=5, stride=2)
+        self.conv3 = conv(128, 256, kernel_size=3, stride=2)
+
+    def forward(self, image):
+        c1 = self.conv1(image)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        return {"conv1": c1, "conv2": c2, "conv3a": c3}, c3
+
+
+class DispnetContextEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv_redir = conv(256, 32, kernel_size=1, stride=1)
+
+    def forward(self, conv3):
+        return self.conv_redir(conv3)
+
+
+class DispnetCostvolumeEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv3_1 = conv(256 + 32, 256)
+        self.conv4 = conv(256, 512, stride=2)
+        self.conv4_1 = conv(512, 512)
+        self.conv5 = conv(512, 512, stride=2)
+        self.conv5_1 = conv(512, 512)
+        self.conv6 = conv(512, 1024, stride=2)
+        self.conv6_1 = conv(1024, 1024)
+
+    def forward(self, corr, ctx):
+        out = {"merged": torch.cat([ctx, corr], 1)}
+        x = out["merged"]
+        for name in ("conv3_1", "conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"):
+            x = getattr(self, name)(x)
+            out[name] = x
+        return out, x
+
+
+def _pred_block(cin):
+    return nn.Sequential(nn.Conv2d(cin, 2, kernel_size=3, stride=1, padding=1, bias=True),
+                         ReLUAndSigmoid(inplace=True, min=-10, max=10))
+
+
+def _deconv(cin, cout):
+    return nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1, bias=True),
+                         nn.LeakyReLU(0.2, inplace=True))
+
+
+def _iconv(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin + 2, cout, kernel_size=3, stride=1, padding=1, bias=True),
+                         nn.LeakyReLU(0.2, inplace=True))
+
+
+class DispnetDecoder(nn.Module):
+    """5-level refinement decoder with an (inverse depth, log b) head per level (dispnet_decoder.py:36-138)."""
+
+    SKIPS = ["conv5_1", "conv4_1", "conv3_1", "conv2", "conv1"]
+    SKIP_CH = [512, 512, 256, 128, 64]
+
+    def __init__(self):
+        super().__init__()
+        ch = 1024
+        self.pred_0 = _pred_block(ch)
+        for lvl, skip_ch in enumerate(self.SKIP_CH, start=1):
+            nxt = ch // 2
+            setattr(self, f"deconv_{lvl}", _deconv(ch, nxt))
+            setattr(self, f"rfeat{lvl}", _iconv(nxt + skip_ch, nxt))
+            setattr(self, f"pred_{lvl}", _pred_block(nxt))
+            ch = nxt
+
+    @staticmethod
+    def _record(pred, preds):
+        mean, log_b = pred[:, 0:1], pred[:, 1:2]
+        ent = torch.log(2 * torch.exp(log_b) + 1e-4) + 1
+        preds.setdefault("invdepth_uncertainties_all", []).append(ent)
+        preds.setdefault("invdepth_log_bs_all", []).append(log_b)
+        preds.setdefault("invdepths_all", []).append(mean)
+        preds["invdepth_uncertainty"], preds["invdepth_log_b"], preds["invdepth"] = ent, log_b, mean
+
+    def forward(self, enc_fused, all_enc):
+        preds = {}
+        feat, pred = enc_fused, self.pred_0(enc_fused)
+        self._record(pred, preds)
+        for lvl, skip in enumerate(self.SKIPS, start=1):
+            up = getattr(self, f"deconv_{lvl}")(feat)
+            pred_up = F.interpolate(pred, size=up.shape[-2:], mode="bilinear", align_corners=False).detach()
+            feat = getattr(self, f"rfeat{lvl}")(torch.cat((all_enc[skip], up, pred_up), 1))
+            pred = getattr(self, f"pred_{lvl}")(feat)
+            self._record(pred, preds)
+        return preds

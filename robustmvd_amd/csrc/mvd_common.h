@@ -1,0 +1,77 @@
+// Shared host/device helpers of libmvd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "mvd.h"
+
+namespace mvd {
+
+void set_error(const char* fmt, ...);
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MVD_ERR_LAUNCH;
+    }
+    return MVD_OK;
+}
+
+#define MVD_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            mvd::set_error(__VA_ARGS__); \
+            return MVD_ERR_INVALID_ARG; \
+        }                               \
+    } while (0)
+
+// per-view device pointers, passed to kernels by value (kernarg segment)
+struct ViewPtrs {
+    const float* p[MVD_MAX_VIEWS];
+};
+struct ViewOutPtrs {
+    float* p[MVD_MAX_VIEWS];
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device: exactly rounded fp32 steps for the sampling-grid arithmetic -----------------------
+// The grids decide which taps are in bounds (a 0/1 mask in Path A), so they follow the reference's
+// operation order with one rounding per operation; the library is built with -ffp-contract=off and
+// the hot accumulation loops ask for FMAs explicitly (fmaf).
+__device__ __forceinline__ float unnormalize_coord(float g, float size) {
+    // ATen grid_sampler_unnormalize, align_corners=False: ((g + 1) * size - 1) / 2
+    return ((g + 1.0f) * size - 1.0f) / 2.0f;
+}
+
+struct Taps {
+    int off[4];  // pixel index (y*ws + x) of nw, ne, sw, se; 0 when out of bounds
+    float w[4];  // bilinear weight; 0 when out of bounds
+    float inb;   // sum of in-bounds weights
+};
+
+// bilinear taps with zero padding at un-normalised source index (ix, iy); NaN/inf coordinates fall
+// out of bounds on every tap (all comparisons false), like ATen's CPU kernel.
+__device__ __forceinline__ Taps bilinear_taps(float ix, float iy, int hs, int ws) {
+    Taps t;
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    const float wx1 = ix - x0, wx0 = x1 - ix, wy1 = iy - y0, wy0 = y1 - iy;
+    const float xs[4] = {x0, x1, x0, x1};
+    const float ys[4] = {y0, y0, y1, y1};
+    const float wt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+    const float xmax = (float)(ws - 1), ymax = (float)(hs - 1);
+    t.inb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool in = (xs[k] >= 0.0f) && (xs[k] <= xmax) && (ys[k] >= 0.0f) && (ys[k] <= ymax);
+        t.off[k] = in ? ((int)ys[k] * ws + (int)xs[k]) : 0;
+        t.w[k] = in ? wt[k] : 0.0f;
+        t.inb += t.w[k];
+    }
+    return t;
+}
+
+}  // namespace mvd

@@ -1,0 +1,56 @@
+// K5 — softmax over the depth axis + soft-argmin depth + 4-bin confidence (Path B).
+// Replaces F.softmax + depth_regression + avg_pool3d/gather of MVSNet.forward
+// (rmvd/models/mvsnet.py:139-160, rmvd/models/blocks/utils.py:271-274).
+// One lane per pixel, lanes along x: every load of a depth plane row is a coalesced 256-B segment.
+// Three sweeps over D (max, sums, 4-bin window); the cost volume is D*h*w*4 B (57 MB at the headline
+// shape) and stays in the Infinity Cache between sweeps, so HBM sees it about once.
+#include "mvd_common.h"
+
+namespace mvd {
+
+__global__ void __launch_bounds__(256) softmax_regress_kernel(const float* __restrict__ cost,
+                                                              const float* __restrict__ depth_values, int D,
+                                                              long long hw, float* __restrict__ depth_out,
+                                                              float* __restrict__ conf_out) {
+    const int b = blockIdx.y;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    const float* c = cost + (long long)b * D * hw + pix;
+    const float* dv = depth_values + (long long)b * D;
+
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, c[(long long)d * hw]);
+    float se = 0.f;
+    for (int d = 0; d < D; ++d) se += expf(c[(long long)d * hw] - m);
+    // p_d = e_d / se exactly as softmax does, then the two expectations (mvsnet.py:140-141,151-154)
+    float depth = 0.f, fidx = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float pd = expf(c[(long long)d * hw] - m) / se;
+        depth = fmaf(pd, dv[d], depth);
+        fidx = fmaf(pd, (float)d, fidx);
+    }
+    depth_out[(long long)b * hw + pix] = depth;
+    if (conf_out) {
+        const int idx = (int)fidx;  // .long(): truncation (mvsnet.py:154)
+        float conf = 0.f;
+#pragma unroll
+        for (int j = -1; j <= 2; ++j) {
+            const int dd = idx + j;
+            if (dd >= 0 && dd < D) conf += expf(c[(long long)dd * hw] - m) / se;
+        }
+        conf_out[(long long)b * hw + pix] = conf;
+    }
+}
+
+}  // namespace mvd
+
+extern "C" int mvd_softmax_regress_f32(const float* cost, const float* depth_values, int B, int D, int h, int w,
+                                       float* depth_out, float* conf_out, mvd_stream_t stream) {
+    MVD_REQUIRE(cost && depth_values && depth_out, "softmax_regress: NULL argument");
+    MVD_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0 && B <= 65535, "softmax_regress: bad dimension");
+    const long long hw = (long long)h * w;
+    dim3 grid((unsigned)((hw + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(mvd::softmax_regress_kernel, grid, dim3(256), 0, (hipStream_t)stream, cost, depth_values, D, hw,
+                       depth_out, conf_out);
+    return mvd::launch_status("softmax_regress");
+}

@@ -1,0 +1,238 @@
+"""Operator-level entry points of the HIP engine on torch (ROCm) tensors.  Each function validates its
+arguments in Python (ValueError), allocates outputs/workspace with torch and calls one C-ABI function of
+libmvd_hip.so on the tensor's device and torch's current stream.  Inference only (no autograd).
+"""
+import torch
+
+from . import _lib as L
+
+
+def _views(ts, name, V=None):
+    ts = list(ts)
+    if len(ts) == 0 or len(ts) > L.MVD_MAX_VIEWS:
+        raise ValueError(f"{name}: {len(ts)} views, supported 1..{L.MVD_MAX_VIEWS}")
+    if V is not None and len(ts) != V:
+        raise ValueError(f"{name}: {len(ts)} entries for {V} views")
+    return ts
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+@torch.no_grad()
+def sweep_corr(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths):
+    """K1. feat_key (N,C,h,w); feat_sources V x (N,C,hs,ws); K_* relative intrinsics (N,3,3);
+    T_src2key V x (N,4,4); invdepths (1 or N, S).  Returns (corrs[V], masks[V]) each (N,S,h,w)."""
+    lib = L.load()
+    fk = L.as_f32(feat_key, "feat_key")
+    if fk.dim() != 4:
+        raise ValueError("feat_key must be (N,C,h,w)")
+    N, C, h, w = fk.shape
+    dev = fk.device
+    srcs = _views(feat_sources, "feat_sources")
+    V = len(srcs)
+    hs, ws = srcs[0].shape[-2:]
+    srcs = [L.as_f32(s, f"feat_sources[{i}]", (N, C, hs, ws), dev) for i, s in enumerate(srcs)]
+    Kk = L.as_f32(K_key, "intrinsics_key", (N, 3, 3), dev)
+    Ks = [L.as_f32(k, f"intrinsics_sources[{i}]", (N, 3, 3), dev) for i, k in enumerate(_views(K_sources, "intrinsics_sources", V))]
+    Ts = [L.as_f32(t, f"source_to_key_transforms[{i}]", (N, 4, 4), dev) for i, t in enumerate(_views(T_src2key, "source_to_key_transforms", V))]
+    inv = L.as_f32(invdepths, "sampling_invdepths", device=dev)
+    if inv.dim() != 2 or inv.shape[0] not in (1, N):
+        raise ValueError(f"sampling_invdepths must be (1 or N, S), got {tuple(inv.shape)}")
+    S = inv.shape[1]
+    if C % 64 != 0:
+        raise ValueError(f"feature channels C={C} must be a multiple of 64")
+    corrs = [torch.empty((N, S, h, w), dtype=torch.float32, device=dev) for _ in range(V)]
+    masks = [torch.empty((N, S, h, w), dtype=torch.float32, device=dev) for _ in range(V)]
+    wsb = lib.mvd_sweep_corr_workspace_bytes(N, C, h, w, hs, ws, V)
+    wsp = _workspace(wsb, dev)
+    a_src, k1 = L.ptr_array(srcs)
+    a_K, k2 = L.ptr_array(Ks)
+    a_T, k3 = L.ptr_array(Ts)
+    a_c, k4 = L.ptr_array(corrs)
+    a_m, k5 = L.ptr_array(masks)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_sweep_corr_f32(L.ptr(fk), a_src, L.ptr(Kk), a_K, a_T, L.ptr(inv), int(inv.shape[0] == N and N > 1),
+                                    N, C, h, w, hs, ws, S, V, a_c, a_m, L.ptr(wsp), wsb, L.stream_of(fk))
+    L.check(rc, "mvd_sweep_corr_f32")
+    return corrs, masks
+
+
+@torch.no_grad()
+def fuse_views(corrs, masks, scores):
+    """K2. corrs, masks V x (N,S,h,w); scores V x (N,1,h,w) -> fused, fused_mask (N,S,h,w)."""
+    lib = L.load()
+    corrs = _views(corrs, "corrs")
+    V = len(corrs)
+    c0 = L.as_f32(corrs[0], "corrs[0]")
+    N, S, h, w = c0.shape
+    dev = c0.device
+    corrs = [L.as_f32(c, f"corrs[{i}]", (N, S, h, w), dev) for i, c in enumerate(corrs)]
+    masks = [L.as_f32(m, f"masks[{i}]", (N, S, h, w), dev) for i, m in enumerate(_views(masks, "masks", V))]
+    scores = [L.as_f32(s, f"scores[{i}]", (N, 1, h, w), dev) for i, s in enumerate(_views(scores, "scores", V))]
+    fused = torch.empty_like(c0)
+    fmask = torch.empty_like(c0)
+    a_c, k1 = L.ptr_array(corrs)
+    a_m, k2 = L.ptr_array(masks)
+    a_s, k3 = L.ptr_array(scores)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_fuse_views_f32(a_c, a_m, a_s, N, S, h, w, V, L.ptr(fused), L.ptr(fmask), L.stream_of(c0))
+    L.check(rc, "mvd_fuse_views_f32")
+    return fused, fmask
+
+
+@torch.no_grad()
+def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, channels_last=False):
+    """K3. key_feat (B,C,h,w); src_feats V x (B,C,h,w); src_projs V x (B,4,4); key_proj_inv (B,4,4);
+    depth_values (B,D).  Returns the variance volume (B,C,D,h,w), or (B,D,h,w,C) if channels_last."""
+    lib = L.load()
+    kf = L.as_f32(key_feat, "key_feat")
+    if kf.dim() != 4:
+        raise ValueError("key_feat must be (B,C,h,w)")
+    B, C, h, w = kf.shape
+    dev = kf.device
+    srcs = [L.as_f32(s, f"src_feats[{i}]", (B, C, h, w), dev) for i, s in enumerate(_views(src_feats, "src_feats"))]
+    V = len(srcs)
+    projs = [L.as_f32(p, f"src_projs[{i}]", (B, 4, 4), dev) for i, p in enumerate(_views(src_projs, "src_projs", V))]
+    kpi = L.as_f32(key_proj_inv, "key_proj_inv", (B, 4, 4), dev)
+    dv = L.as_f32(depth_values, "depth_values", device=dev)
+    if dv.dim() != 2 or dv.shape[0] != B:
+        raise ValueError(f"depth_values must be (B,D), got {tuple(dv.shape)}")
+    D = dv.shape[1]
+    if C not in (4, 8, 16, 32, 64):
+        raise ValueError(f"feature channels C={C} unsupported (4, 8, 16, 32, 64)")
+    shape = (B, D, h, w, C) if channels_last else (B, C, D, h, w)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    wsb = lib.mvd_warp_variance_workspace_bytes(B, C, h, w, V)
+    wsp = _workspace(wsb, dev)
+    a_s, k1 = L.ptr_array(srcs)
+    a_p, k2 = L.ptr_array(projs)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_warp_variance_f32(L.ptr(kf), a_s, a_p, L.ptr(kpi), L.ptr(dv), B, C, D, h, w, V, L.ptr(out),
+                                       L.LAYOUT_NDHWC if channels_last else L.LAYOUT_NCDHW, L.ptr(wsp), wsb,
+                                       L.stream_of(kf))
+    L.check(rc, "mvd_warp_variance_f32")
+    return out
+
+
+@torch.no_grad()
+def homo_warp(src_feat, src_proj, ref_proj_inv, depth_values):
+    """Drop-in for rmvd.models.blocks.utils.homo_warp (blocks/utils.py:222): -> (B,C,D,H,W)."""
+    lib = L.load()
+    sf = L.as_f32(src_feat, "src_feat")
+    if sf.dim() != 4:
+        raise ValueError("src_feat must be (B,C,H,W)")
+    B, C, h, w = sf.shape
+    dev = sf.device
+    sp = L.as_f32(src_proj, "src_proj", (B, 4, 4), dev)
+    kpi = L.as_f32(ref_proj_inv, "ref_proj_inv", (B, 4, 4), dev)
+    dv = L.as_f32(depth_values, "depth_values", device=dev)
+    if dv.dim() != 2 or dv.shape[0] != B:
+        raise ValueError(f"depth_values must be (B,D), got {tuple(dv.shape)}")
+    D = dv.shape[1]
+    if C not in (4, 8, 16, 32, 64):
+        raise ValueError(f"feature channels C={C} unsupported (4, 8, 16, 32, 64)")
+    out = torch.empty((B, C, D, h, w), dtype=torch.float32, device=dev)
+    wsb = lib.mvd_warp_variance_workspace_bytes(B, C, h, w, 0)
+    wsp = _workspace(wsb, dev)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_homo_warp_f32(L.ptr(sf), L.ptr(sp), L.ptr(kpi), L.ptr(dv), B, C, D, h, w, L.ptr(out), L.ptr(wsp),
+                                   wsb, L.stream_of(sf))
+    L.check(rc, "mvd_homo_warp_f32")
+    return out
+
+
+@torch.no_grad()
+def pack_conv3d_weights(weight, mode):
+    """weight: Conv3d (Cout,Cin,3,3,3) or, for mode DECONV3D_STRIDE2, ConvTranspose3d (Cin,Cout,3,3,3)."""
+    lib = L.load()
+    wt = L.as_f32(weight, "weight")
+    if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"weight must be (*,*,3,3,3), got {tuple(wt.shape)}")
+    if mode == L.DECONV3D_STRIDE2:
+        Cin, Cout = wt.shape[0], wt.shape[1]
+    else:
+        Cout, Cin = wt.shape[0], wt.shape[1]
+    n = lib.mvd_conv3d_packed_weight_floats(Cin, Cout)
+    if n == 0:
+        raise ValueError(f"conv3d: Cin={Cin}, Cout={Cout} unsupported (Cin in 8/16/32/64, Cout in 1/8/16/32/64)")
+    packed = torch.empty(n, dtype=torch.float32, device=wt.device)
+    with torch.cuda.device(wt.device):
+        rc = lib.mvd_pack_conv3d_weights_f32(L.ptr(wt), Cin, Cout, mode, L.ptr(packed), L.stream_of(wt))
+    L.check(rc, "mvd_pack_conv3d_weights_f32")
+    return packed, Cin, Cout
+
+
+@torch.no_grad()
+def conv3d_bn_relu(x, packed, Cin, Cout, scale, shift, mode, relu=True, skip=None):
+    """K4. x (B,D,h,w,Cin) channel-last -> (B,Do,ho,wo,Cout)."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    if x.dim() != 5 or x.shape[-1] != Cin:
+        raise ValueError(f"x must be (B,D,h,w,{Cin}) channel-last, got {tuple(x.shape)}")
+    B, Di, hi, wi, _ = x.shape
+    dev = x.device
+    if mode == L.CONV3D_STRIDE1:
+        oshape = (B, Di, hi, wi, Cout)
+    elif mode == L.CONV3D_STRIDE2:
+        if Di % 2 or hi % 2 or wi % 2:
+            raise ValueError(f"stride-2 conv needs even D,h,w, got {Di},{hi},{wi}")
+        oshape = (B, Di // 2, hi // 2, wi // 2, Cout)
+    elif mode == L.DECONV3D_STRIDE2:
+        oshape = (B, Di * 2, hi * 2, wi * 2, Cout)
+    else:
+        raise ValueError(f"mode {mode}")
+    scale = L.as_f32(scale, "scale", (Cout,), dev)
+    shift = L.as_f32(shift, "shift", (Cout,), dev)
+    if skip is not None:
+        skip = L.as_f32(skip, "skip", oshape, dev)
+    y = torch.empty(oshape, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_conv3d_bn_relu_f32(L.ptr(x), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(skip), L.ptr(y), B, Di,
+                                        hi, wi, Cin, Cout, mode, int(bool(relu)), L.stream_of(x))
+    L.check(rc, "mvd_conv3d_bn_relu_f32")
+    return y
+
+
+@torch.no_grad()
+def softmax_regress(cost, depth_values, with_confidence=True):
+    """K5. cost (B,D,h,w); depth_values (B,D) -> depth (B,h,w), confidence (B,h,w) or None."""
+    lib = L.load()
+    c = L.as_f32(cost, "cost")
+    if c.dim() != 4:
+        raise ValueError("cost must be (B,D,h,w)")
+    B, D, h, w = c.shape
+    dv = L.as_f32(depth_values, "depth_values", (B, D), c.device)
+    depth = torch.empty((B, h, w), dtype=torch.float32, device=c.device)
+    conf = torch.empty((B, h, w), dtype=torch.float32, device=c.device) if with_confidence else None
+    with torch.cuda.device(c.device):
+        rc = lib.mvd_softmax_regress_f32(L.ptr(c), L.ptr(dv), B, D, h, w, L.ptr(depth), L.ptr(conf), L.stream_of(c))
+    L.check(rc, "mvd_softmax_regress_f32")
+    return depth, conf
+
+
+@torch.no_grad()
+def to_channels_last_3d(x):
+    """(B,C,D,h,w) -> (B,D,h,w,C) through the library's tiled transpose."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    B, C, D, h, w = x.shape
+    y = torch.empty((B, D, h, w, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mvd_nchw_to_nhwc_f32(L.ptr(x), L.ptr(y), B, C, D * h * w, L.stream_of(x))
+    L.check(rc, "mvd_nchw_to_nhwc_f32")
+    return y
+
+
+@torch.no_grad()
+def from_channels_last_3d(y):
+    """(B,D,h,w,C) -> (B,C,D,h,w)."""
+    lib = L.load()
+    y = L.as_f32(y, "y")
+    B, D, h, w, C = y.shape
+    x = torch.empty((B, C, D, h, w), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = lib.mvd_nhwc_to_nchw_f32(L.ptr(y), L.ptr(x), B, C, D * h * w, L.stream_of(y))
+    L.check(rc, "mvd_nhwc_to_nchw_f32")
+    return x

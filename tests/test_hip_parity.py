@@ -1,0 +1,209 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the golden vectors of the reference's CPU
+path and against the CPU oracle on identical seeded inputs.  Tolerances: SURVEY.md 8(c) — block outputs
+atol = rtol = 1e-4 (fp32), masks exact up to samples within 1e-4 px of a border, regressed depth rtol 1e-3
+(Path B, 11 conv layers), Path A final prediction compared in inverse-depth space at atol 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+import gen_common as gc
+from conftest import load_golden, unpack_mask
+from test_oracle_golden import (_sweep_inputs, check_sweep_outputs, costreg_shapes, fusion_inputs, fusion_weights)
+
+pytestmark = pytest.mark.gpu
+ATOL = RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+@pytest.mark.parametrize("name,V", [("g2_sweep_toy", 2), ("g2_sweep_rot", 1), ("g2_sweep_behind", 1),
+                                    ("g2_sweep_c256", 2), ("g2_sweep_cfg1", 1)])
+def test_sweep_corr_golden(name, V, dev):
+    import robustmvd_amd as R
+    g = load_golden(name)
+    fk, fs, Kk, Ks, Ts = _sweep_inputs(g, V)
+    inv = g["invdepths"][:, :, 0, 0]
+    C = fk.shape[1]
+    if C % 64:  # the engine needs C % 64 == 0: zero-pad the channel axis, rescale for 1/sqrt(C)
+        pad = 64 - C % 64
+        fk = np.pad(fk, ((0, 0), (0, pad), (0, 0), (0, 0)))
+        fs = [np.pad(f, ((0, 0), (0, pad), (0, 0), (0, 0))) for f in fs]
+        rescale = np.sqrt((C + pad) / C).astype(np.float32)
+    else:
+        rescale = np.float32(1.0)
+    blk = R.PlanesweepCorrelation()
+    corrs, masks, inv_out = blk(T(fk, dev), T(Kk, dev), [T(f, dev) for f in fs], [T(t, dev) for t in Ts],
+                                [T(k, dev) for k in Ks], sampling_invdepths=T(inv, dev))
+    assert tuple(inv_out.shape) == g["invdepths"].shape
+    check_sweep_outputs(g, V, [c.cpu().numpy() * rescale for c in corrs], [m.cpu().numpy() for m in masks])
+
+
+def test_sweep_corr_range_arguments(dev):
+    """(num_sampling_points, min_depth, max_depth) form == explicit invdepths; bad combinations raise."""
+    import robustmvd_amd as R
+    g = load_golden("g2_sweep_c256")
+    fk, fs, Kk, Ks, Ts = _sweep_inputs(g, 2)
+    blk = R.PlanesweepCorrelation()
+    args = (T(fk, dev), T(Kk, dev), [T(f, dev) for f in fs], [T(t, dev) for t in Ts])
+    c1, m1, inv = blk(*args, num_sampling_points=64, min_depth=0.4, max_depth=1000.0)
+    np.testing.assert_allclose(inv.cpu().numpy(), g["invdepths"], rtol=1e-6)
+    check_sweep_outputs(g, 2, [c.cpu().numpy() for c in c1], [m.cpu().numpy() for m in m1])
+    with pytest.raises(ValueError):
+        blk(*args, num_sampling_points=64)
+    with pytest.raises(ValueError):
+        blk(*args, num_sampling_points=64, min_depth=0.4, max_depth=10.0, sampling_invdepths=inv)
+
+
+@pytest.mark.parametrize("V", [1, 2, 4])
+def test_fusion_golden(V, dev):
+    import robustmvd_amd as R
+    g = load_golden("g3_fusion")
+    m = R.LearnedFusion().to(dev).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in fusion_weights().items()})
+    corrs, masks = fusion_inputs(V)
+    with torch.no_grad():
+        fused, fmask = m([T(c, dev) for c in corrs], [T(x, dev) for x in masks])
+    ref = g[f"V{V}_fused"]
+    assert (fmask.cpu().numpy() == unpack_mask(g[f"V{V}_fmask"], ref.shape)).all()
+    # the score convs run on MIOpen (fp32): allow its accumulation-order noise on top of the block tolerance
+    np.testing.assert_allclose(fused.cpu().numpy(), ref, atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("name,V", [("g4_warpvar_a", 1), ("g4_warpvar_b", 2), ("g4_warpvar_c", 2)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_warp_variance_golden(name, V, channels_last, dev):
+    from robustmvd_amd import ops
+    g = load_golden(name)
+    feats = [T(g[f"feat{i}"], dev) for i in range(V + 1)]
+    projs = [T(g[f"src_proj{v}"], dev) for v in range(V)]
+    var = ops.warp_variance(feats[0], feats[1:], projs, T(g["key_proj_inv"], dev), T(g["depth_values"], dev),
+                            channels_last=channels_last)
+    if channels_last:
+        var = var.permute(0, 4, 1, 2, 3)
+    np.testing.assert_allclose(var.cpu().numpy(), g["variance"], atol=ATOL, rtol=RTOL)
+    if "warped0" in g.files and not channels_last:
+        w0 = ops.homo_warp(feats[1], projs[0], T(g["key_proj_inv"], dev), T(g["depth_values"], dev))
+        np.testing.assert_allclose(w0.cpu().numpy(), g["warped0"], atol=ATOL, rtol=RTOL)
+
+
+def load_costreg(dev, seed):
+    import robustmvd_amd as R
+    net = R.CostRegNet().eval()
+    sd = gc.fill_state_dict(costreg_shapes(), seed)
+    full = net.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    net.load_state_dict(full)
+    return net.to(dev), sd
+
+
+def test_costreg_golden(dev):
+    from robustmvd_amd import ops
+    from robustmvd_amd import _lib as L
+    g = load_golden("g5_costreg")
+    net, sd = load_costreg(dev, int(g["weight_seed"]))
+    x = np.abs(gc.rng_array(int(g["x_seed"]), (1, 32, 16, 16, 24), 0.7))
+    xt = T(x, dev)
+    # first two layers separately (stride 1 and stride 2), then the whole U-Net
+    pk = net._prepare()
+    xcl = ops.to_channels_last_3d(xt)
+    w, cin, cout, sc, sh, mode = pk["conv0"]
+    c0 = ops.conv3d_bn_relu(xcl, w, cin, cout, sc, sh, mode)
+    np.testing.assert_allclose(c0.permute(0, 4, 1, 2, 3).cpu().numpy(), g["conv0"], atol=ATOL, rtol=RTOL)
+    w, cin, cout, sc, sh, mode = pk["conv1"]
+    c1 = ops.conv3d_bn_relu(c0, w, cin, cout, sc, sh, mode)
+    np.testing.assert_allclose(c1.permute(0, 4, 1, 2, 3).cpu().numpy(), g["conv1"], atol=ATOL, rtol=RTOL)
+    out = net(xt)
+    assert tuple(out.shape) == (1, 1, 16, 16, 24)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], atol=2e-4, rtol=1e-3)
+
+
+def test_channels_last_roundtrip(dev):
+    from robustmvd_amd import ops
+    x = torch.randn(2, 8, 5, 7, 9, device=dev)
+    y = ops.to_channels_last_3d(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 4, 1).contiguous())
+    assert torch.equal(ops.from_channels_last_3d(y), x)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_softmax_regress_golden(name, dev):
+    from robustmvd_amd import ops
+    g = load_golden("g6_regress")
+    B, D, h, w = g[f"{name}_shape"]
+    cost = gc.rng_array(int(g[f"{name}_seed"]), (B, D, h, w), float(g[f"{name}_scale"]))
+    dv = np.stack([np.linspace(0.5, 10.0, D, dtype=np.float32)] * B)
+    depth, conf = ops.softmax_regress(T(cost, dev), T(dv, dev))
+    np.testing.assert_allclose(depth.cpu().numpy(), g[f"{name}_depth"], atol=1e-5, rtol=1e-5)
+    # confidence depends on trunc(E[idx]); an expectation within rounding of an integer may land in the next bin
+    close = np.isclose(conf.cpu().numpy(), g[f"{name}_conf"], atol=1e-5, rtol=1e-5)
+    assert close.mean() > 0.999
+
+
+def load_robustmvd(dev, seed):
+    import robustmvd_amd as R
+    model = R.RobustMVD().eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in gc.robustmvd_weights(shapes, seed).items()})
+    model = model.to(dev)
+    R.add_run_function(model)
+    return model
+
+
+def test_robustmvd_end_to_end_golden(dev):
+    """create_model-protocol run() on the reference's sample_data pair at 384x576 (BASELINE config 1)."""
+    g = load_golden("g7_robustmvd")
+    model = load_robustmvd(dev, int(g["weight_seed"]))
+    sample = dict(images=[g["image_key"].astype(np.float32), g["image_src0"].astype(np.float32)],
+                  intrinsics=[g["K"].copy(), g["K"].copy()],
+                  poses=[np.eye(4, dtype=np.float32), g["T0"]], keyview_idx=0)
+    pred, aux = model.run(**sample)
+    assert pred["depth"].shape == (1, 192, 288)
+    # 2-D convs run on MIOpen here and on oneDNN in the reference: their fp32 accumulation order differs,
+    # so the end-to-end tolerance is wider than the block tolerance (inverse-depth space)
+    np.testing.assert_allclose(aux["invdepth"], g["invdepth"], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(aux["invdepths_all"][0], g["invdepths_all_0"], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(aux["invdepths_all"][3], g["invdepths_all_3"], atol=2e-3, rtol=2e-3)
+    valid = g["invdepth"][0] > 1e-2
+    np.testing.assert_allclose(pred["depth"][0][valid], g["depth"][0][valid], rtol=5e-2)
+
+
+def test_robustmvd_two_sources_golden(dev):
+    g = load_golden("g7_robustmvd_v2")
+    model = load_robustmvd(dev, int(g["weight_seed"]))
+    H2, W2 = 128, 192
+    rng = np.random.default_rng(int(g["seed"]))
+    images = [rng.uniform(0, 255, (3, H2, W2)).astype(np.float32) for _ in range(3)]
+    K2 = gc.synthetic_intrinsics(H2, W2)
+    poses = [gc.synthetic_pose(rng), np.eye(4, dtype=np.float32), gc.synthetic_pose(rng)]
+    pred, aux = model.run(images=images, intrinsics=[K2, K2, K2], poses=poses, keyview_idx=1)
+    np.testing.assert_allclose(aux["invdepth"], g["invdepth"], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=2e-3, rtol=2e-3)
+
+
+def test_mvsnet_end_to_end_golden(dev):
+    import robustmvd_amd as R
+    g = load_golden("g8_mvsnet")
+    H, W, D, V = g["shape"]
+    model = R.MVSNet(num_sampling_steps=int(D)).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    full = model.state_dict()
+    for k, v in gc.fill_state_dict(shapes, int(g["weight_seed"])).items():
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    model = model.to(dev)
+    R.add_run_function(model)
+    s = gc.synthetic_sample(int(g["sample_seed"]), int(H), int(W), int(V))
+    pred, _ = model.run(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0,
+                        depth_range=(np.float32(0.5), np.float32(10.0)))
+    np.testing.assert_allclose(pred["depth"][None], g["depth"], rtol=1e-3)   # Path B depth rtol 1e-3
+    np.testing.assert_allclose(pred["depth_uncertainty"][None], g["depth_uncertainty"], atol=2e-3)
