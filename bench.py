@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: depth-maps/sec through the MVSNet-style plane-sweep path (warp+variance ->
+3-D regulariser -> soft argmin, with its 2-D feature net) at the ETH3D shape 768x1152, 4 source views,
+256 depth planes, fp32 (BASELINE.json configs[2]), on N GPUs of one node as independent replicas.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one forward pass (one key view + V sources -> one depth map) on inputs already resident in HBM.
+Frames are sharded over the ranks (each rank runs K steps on its own frames, weak scaling); there is no
+data-path collective — the process group is only used for the barrier and the max-over-ranks time.
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (warp+variance kernel, HIP events
+around every launch of it inside the timed region), `cpu_baseline` (the CPU oracle port timed on this
+host, N=1 only) and `path_a` (the robust_mvd model at the same shape, same protocol).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import gen_common as gc  # noqa: E402
+
+CONFIGS = {  # BASELINE.json configs (index -> H, W, V, D)
+    1: (448, 640, 2, 128),
+    2: (768, 1152, 4, 256),
+    3: (896, 1216, 4, 256),
+    4: (704, 1280, 6, 512),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def build_mvsnet(D, dev, seed=0):
+    import robustmvd_amd as R
+    model = R.MVSNet(num_sampling_steps=D).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.fill_state_dict(shapes, seed)
+    full = model.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    return R.add_run_function(model.to(dev)), sd
+
+
+def build_robustmvd(dev, seed=0):
+    import robustmvd_amd as R
+    model = R.RobustMVD().eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.robustmvd_weights(shapes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return R.add_run_function(model.to(dev)), sd
+
+
+def adapted_sample(model, frame_idx, H, W, V, depth_range=None):
+    s = gc.synthetic_sample(frame_idx, H, W, V)
+    from robustmvd_amd.registry import add_batch_dim
+    images, key, poses, intr, dr = add_batch_dim(s["images"], s["keyview_idx"], s["poses"], s["intrinsics"], depth_range)
+    return model.input_adapter(images=images, keyview_idx=key, poses=poses, intrinsics=intr, depth_range=dr)
+
+
+def timed_loop(model, samples, steps, warmup, world, dev, arm=None):
+    """W untimed + K timed forwards bracketed by barrier + synchronize; returns seconds (max over ranks)."""
+    import torch.distributed as dist
+    with torch.no_grad():
+        for i in range(warmup):
+            model(**samples[i % len(samples)])
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if arm is not None:
+                arm(i)
+            model(**samples[i % len(samples)])
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def measured_copy_gbs(dev):
+    """Attainable HBM bandwidth on this box: device-to-device copy of 1 GiB (read + write bytes / time)."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2 * 4 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def cpu_baseline(H, W, V, D, sd):
+    """The CPU oracle port (C/OpenMP hot path + torch-CPU 2-D feature net) on ONE full frame of the workload."""
+    from oracle import c_oracle as CO
+    from oracle import pipeline as PL
+    s = gc.synthetic_sample(0, H, W, V)
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
+    images = [((im / 255.0 - mean) / std).astype(np.float32)[None] for im in s["images"]]
+    timings = {}
+    t0 = time.perf_counter()
+    PL.mvsnet_forward(images, [p[None] for p in s["poses"]], [k[None] for k in s["intrinsics"]], 0, (0.5, 10.0), sd, D,
+                      timings=timings)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "depth-maps/sec", "cores": CO.num_threads(), "kind": "port",
+            "sample": f"1 full frame {H}x{W} V{V} D{D} (one forward, {dt:.1f} s; oracle/pipeline.py: C/OpenMP warp+variance "
+                      f"{timings['warp_variance']:.1f} s, CostRegNet {timings['cost_reg']:.1f} s, soft-argmin "
+                      f"{timings['regress']:.2f} s, torch-CPU FeatureNet {timings['features']:.1f} s)",
+            "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, help="index into BASELINE.json configs (default 2 = headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-path-a", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the engine)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    H, W, V, D = CONFIGS[args.config]
+    h, w, C = H // 4, W // 4, 32
+    model, sd = build_mvsnet(D, dev)
+    # this rank's frames: frame index = rank + world * i (round-robin shard of the frame list)
+    nframes = 2
+    samples = [adapted_sample(model, rank + world * i, H, W, V, (np.float32(0.5), np.float32(10.0))) for i in range(nframes)]
+
+    # HIP events around every warp+variance launch inside the timed region
+    from robustmvd_amd import _lib as L
+    lib = L.load()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:  # force creation of the underlying hipEvent_t
+        a.record(); b.record()
+    torch.cuda.synchronize(dev)
+
+    def arm(i):
+        lib.mvd_arm_kernel_timing(ev[i][0].cuda_event, ev[i][1].cuda_event)
+
+    dt = timed_loop(model, samples, args.steps, args.warmup, world, dev, arm)
+    k3_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    k3_bytes = 4.0 * ((V + 1) * C * h * w + C * D * h * w)  # SURVEY.md 8(d), batch 1 per launch
+    value = world * args.steps / dt
+
+    out = {
+        "metric": "depth-maps/sec at 768x1152x4srcx256planes; warp+aggregate HBM GB/s vs roofline",
+        "value": value, "unit": "depth-maps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"mvsnet (Path B) forward {H}x{W}, {V} source views, {D} planes, batch 1 per step "
+                               f"(BASELINE.json configs[{args.config}])",
+                   "parallelism": f"{world} independent replica(s), frames round-robin, no collectives"},
+    }
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k3_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("config") == args.config:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "hbm", "kernel": "warp_variance_kernel (K3)", "achieved": k3_bytes / (k3_ms * 1e-3) / 1e9,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k3_bytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic": traffic, "algorithmic_bytes_per_launch": k3_bytes, "avg_launch_ms": k3_ms,
+                           "launches_timed": args.steps, "measured_copy_peak_gbs": measured_copy_gbs(dev)}
+    del samples
+    torch.cuda.empty_cache()
+
+    if not args.no_path_a and args.config in (1, 2, 3):
+        # robust_mvd (Path A, the create_model("robust_mvd") drop-in) at the same image shape; S = 256 planes fixed
+        ma, _ = build_robustmvd(dev)
+        sa = [adapted_sample(ma, rank + world * i, H, W, V) for i in range(nframes)]
+        eva = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in eva:
+            a.record(); b.record()
+        torch.cuda.synchronize(dev)
+        dta = timed_loop(ma, sa, args.steps, args.warmup, world, dev,
+                         lambda i: lib.mvd_arm_kernel_timing(eva[i][0].cuda_event, eva[i][1].cuda_event))
+        k1_ms = float(np.mean([a.elapsed_time(b) for a, b in eva]))
+        hs, ws_ = H // 8, W // 8
+        k1_bytes = 4.0 * ((V + 1) * 256 * hs * ws_ + 2 * V * 256 * hs * ws_)
+        out["path_a"] = {"model": "robust_mvd", "value": world * args.steps / dta, "unit": "depth-maps/sec",
+                         "ms_per_step": dta / args.steps * 1e3, "sweep_corr_ms": k1_ms,
+                         "sweep_corr_algorithmic_gbs": k1_bytes / (k1_ms * 1e-3) / 1e9,
+                         "sweep_corr_gflops": V * 256 * hs * ws_ * 256 * 10 / (k1_ms * 1e-3) / 1e9}
+        del ma, sa
+        torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(H, W, V, D, sd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

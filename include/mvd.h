@@ -138,6 +138,12 @@ int mvd_conv3d_bn_relu_f32(const float* x, const float* packed_w, const float* s
 int mvd_softmax_regress_f32(const float* cost, const float* depth_values, int B, int D, int h, int w,
                             float* depth_out, float* conf_out, mvd_stream_t stream);
 
+/* Measurement hook (bench.py): arms a pair of hipEvent_t for THIS thread; the next mvd_warp_variance_f32,
+ * mvd_homo_warp_f32 or mvd_sweep_corr_f32 call records `start` on its stream immediately before its main kernel
+ * (after the small feature re-packing launches) and `stop` immediately after it, then disarms.  Pass NULLs to
+ * disarm.  Nothing is synchronised; the caller reads the events after synchronising the stream. */
+int mvd_arm_kernel_timing(void* start_event, void* stop_event);
+
 /* layout helpers used at the operator-level boundary (reference tensors are NCHW / NCDHW) */
 int mvd_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);
 int mvd_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);

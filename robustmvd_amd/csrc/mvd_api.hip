@@ -10,6 +10,15 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void timing_begin(hipStream_t st) {
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, st);
+}
+void timing_end(hipStream_t st) {
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
+    g_ev_start = g_ev_stop = nullptr;
+}
+
 // (N, C, HW) <-> (N, HW, C) through a 32x33 LDS tile: both sides move 128-B rows.
 __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                         long long rows, long long cols) {
@@ -55,6 +64,11 @@ int transpose_launch(const float* src, float* dst, int N, long long rows, long l
 extern "C" {
 int mvd_version(void) { return MVD_VERSION; }
 const char* mvd_last_error(void) { return mvd::g_err; }
+int mvd_arm_kernel_timing(void* start_event, void* stop_event) {
+    mvd::g_ev_start = (hipEvent_t)start_event;
+    mvd::g_ev_stop = (hipEvent_t)stop_event;
+    return MVD_OK;
+}
 
 int mvd_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream) {
     MVD_REQUIRE(src && dst && N > 0 && C > 0 && HW > 0, "nchw_to_nhwc: bad argument");

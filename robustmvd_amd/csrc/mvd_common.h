@@ -9,6 +9,9 @@
 namespace mvd {
 
 void set_error(const char* fmt, ...);
+// measurement hook (mvd_arm_kernel_timing): record the armed events around a main-kernel launch
+void timing_begin(hipStream_t st);
+void timing_end(hipStream_t st);
 
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();

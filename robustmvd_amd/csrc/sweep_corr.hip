@@ -213,6 +213,7 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
     p.invd_stride = invdepth_batched ? S : 0;
     p.N = N; p.h = h; p.w = w; p.hs = hs; p.ws = ws; p.S = S; p.V = V;
     dim3 grid((unsigned)((w + mvd::SWEEP_PX - 1) / mvd::SWEEP_PX), (unsigned)h, (unsigned)(N * V));
+    mvd::timing_begin(st);
     switch (C / 64) {
 #define MVD_CASE(NJ)                                                                                          \
     case NJ:                                                                                                  \
@@ -225,6 +226,7 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
         MVD_CASE(1) MVD_CASE(2) MVD_CASE(3) MVD_CASE(4) MVD_CASE(5) MVD_CASE(6) MVD_CASE(7) MVD_CASE(8)
 #undef MVD_CASE
     }
+    mvd::timing_end(st);
     return mvd::launch_status("sweep_corr");
 }
 }

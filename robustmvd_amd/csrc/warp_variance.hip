@@ -133,6 +133,7 @@ static int launch_warp(const WarpParams& p, int C, hipStream_t st) {
     const int lpp = C / 4;
     const int ppb = 256 / lpp;
     dim3 grid((unsigned)((p.w + ppb - 1) / ppb), (unsigned)p.h, (unsigned)(p.B * p.D));
+    timing_begin(st);
     switch (lpp) {
 #define MVD_CASE(L)                                                                                  \
     case L:                                                                                          \
@@ -144,6 +145,7 @@ static int launch_warp(const WarpParams& p, int C, hipStream_t st) {
             set_error("warp_variance: C=%d unsupported (need 4, 8, 16, 32 or 64)", C);
             return MVD_ERR_INVALID_ARG;
     }
+    timing_end(st);
     return launch_status("warp_variance");
 }
 

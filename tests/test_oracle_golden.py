@@ -143,3 +143,92 @@ def test_g6_regress(name):
     same = idx == g[f"{name}_idx"]
     assert same.mean() > 0.999  # an expected index within float rounding of an integer may truncate differently
     np.testing.assert_allclose(conf[same], g[f"{name}_conf"][same], atol=1e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# the C/OpenMP part of the oracle (oracle/mvd_oracle_c.c) against the same golden vectors
+# ------------------------------------------------------------------------------------------------
+from oracle import c_oracle as CO  # noqa: E402
+
+
+@pytest.mark.parametrize("name,V", [("g2_sweep_toy", 2), ("g2_sweep_rot", 1), ("g2_sweep_behind", 1),
+                                    ("g2_sweep_c256", 2), ("g2_sweep_cfg1", 1)])
+def test_c_oracle_sweep(name, V):
+    g = load_golden(name)
+    fk, fs, Kk, Ks, Ts = _sweep_inputs(g, V)
+    corrs, masks = CO.sweep_corr(fk, fs, Kk, Ks, Ts, g["invdepths"][:, :, 0, 0])
+    check_sweep_outputs(g, V, corrs, masks)
+
+
+@pytest.mark.parametrize("V", [2, 4])
+def test_c_oracle_fusion(V):
+    g = load_golden("g3_fusion")
+    sd = fusion_weights()
+    corrs, masks = fusion_inputs(V)
+    scores = [O.fusion_scores(c, sd["corr_to_view_weight.0.weight"], sd["corr_to_view_weight.0.bias"],
+                              sd["corr_to_view_weight.2.weight"], sd["corr_to_view_weight.2.bias"]) for c in corrs]
+    fused, fmask = CO.fuse_views(corrs, masks, scores)
+    ref_fused = g[f"V{V}_fused"]
+    assert (fmask == unpack_mask(g[f"V{V}_fmask"], ref_fused.shape)).all()
+    np.testing.assert_allclose(fused, ref_fused, atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("name,V", [("g4_warpvar_a", 1), ("g4_warpvar_b", 2), ("g4_warpvar_c", 2)])
+def test_c_oracle_warp_variance(name, V):
+    g = load_golden(name)
+    feats = [g[f"feat{i}"] for i in range(V + 1)]
+    projs = [g[f"src_proj{v}"] for v in range(V)]
+    if "warped0" in g.files:
+        w0 = CO.homo_warp(feats[1], projs[0], g["key_proj_inv"], g["depth_values"])
+        np.testing.assert_allclose(w0, g["warped0"], atol=ATOL, rtol=RTOL)
+    var = CO.warp_variance(feats[0], feats[1:], projs, g["key_proj_inv"], g["depth_values"])
+    np.testing.assert_allclose(var, g["variance"], atol=ATOL, rtol=RTOL)
+
+
+def test_c_oracle_costreg_and_regress():
+    g = load_golden("g5_costreg")
+    sd = gc.fill_state_dict(costreg_shapes(), int(g["weight_seed"]))
+    x = np.abs(gc.rng_array(int(g["x_seed"]), (1, 32, 16, 16, 24), 0.7))
+    out = CO.cost_reg_net(x, sd)
+    np.testing.assert_allclose(out, g["out"], atol=2e-4, rtol=1e-3)
+    g6 = load_golden("g6_regress")
+    B, D, h, w = g6["a_shape"]
+    cost = gc.rng_array(int(g6["a_seed"]), (B, D, h, w), float(g6["a_scale"]))
+    dv = np.stack([np.linspace(0.5, 10.0, D, dtype=np.float32)] * B)
+    depth, conf = CO.softmax_regress(cost, dv)
+    np.testing.assert_allclose(depth, g6["a_depth"], atol=1e-5, rtol=1e-5)
+    assert np.isclose(conf, g6["a_conf"], atol=1e-5, rtol=1e-5).mean() > 0.999
+
+
+# ------------------------------------------------------------------------------------------------
+# end-to-end oracle pipelines (hot path on the C oracle, adjacent 2-D CNN on torch CPU)
+# ------------------------------------------------------------------------------------------------
+def test_pipeline_mvsnet_g8():
+    import robustmvd_amd as R
+    from oracle import pipeline as PL
+    g = load_golden("g8_mvsnet")
+    H, W, D, V = (int(v) for v in g["shape"])
+    shapes = {k: tuple(v.shape) for k, v in R.MVSNet(num_sampling_steps=D).state_dict().items()}
+    sd = gc.fill_state_dict(shapes, int(g["weight_seed"]))
+    s = gc.synthetic_sample(int(g["sample_seed"]), H, W, V)
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
+    images = [((im / 255.0 - mean) / std).astype(np.float32)[None] for im in s["images"]]
+    pred = PL.mvsnet_forward(images, [p[None] for p in s["poses"]], [k[None] for k in s["intrinsics"]], 0,
+                             (0.5, 10.0), sd, D)
+    np.testing.assert_allclose(pred["depth"], g["depth"], rtol=1e-3)
+    np.testing.assert_allclose(pred["depth_uncertainty"], g["depth_uncertainty"], atol=2e-3)
+
+
+def test_pipeline_robustmvd_g7():
+    import robustmvd_amd as R
+    from oracle import pipeline as PL
+    g = load_golden("g7_robustmvd")
+    shapes = {k: tuple(v.shape) for k, v in R.RobustMVD().state_dict().items()}
+    sd = gc.robustmvd_weights(shapes, int(g["weight_seed"]))
+    H, W = 384, 576
+    images = [(g[k].astype(np.float32) / 255.0 - 0.4)[None] for k in ("image_key", "image_src0")]
+    K_rel = (g["K"] / np.array([[W] * 3, [H] * 3, [1.0] * 3], np.float32))[None]
+    pred = PL.robustmvd_forward(images, [np.eye(4, dtype=np.float32)[None], g["T0"][None]], [K_rel, K_rel], 0, sd)
+    np.testing.assert_allclose(pred["invdepth"], g["invdepth"][None], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(pred["invdepth_log_b"], g["invdepth_log_b"][None], atol=1e-4, rtol=1e-4)
