@@ -5,151 +5,347 @@
 //
 // HBM-bound by construction: the only large tensor is the variance volume, written exactly once
 // (algorithmic bytes 4*((V+1)*C*h*w + C*D*h*w) per batch element); the per-view warped volumes of the
-// reference are never materialised.  Feature maps are first repacked channel-last ((h,w,C), 128 B per
-// pixel at C=32) so that one bilinear tap of one pixel is a single full cache line shared by C/4 lanes.
+// reference are never materialised.  Feature maps are first repacked channel-last with a zero border
+// ((h+3,w+3,C), 128 B per pixel at C=32): one bilinear tap of one pixel is a single full cache line shared
+// by C/4 lanes, and zero padding costs no in-bounds logic (the clamped sample position lands on zero taps).
 //
 // Thread mapping: C/4 lanes per output pixel (each lane owns 4 channels = one 16-B load per tap),
 // 256/(C/4) consecutive x pixels per workgroup, one (b, d, y) row segment per workgroup.
 #include "mvd_common.h"
+#include <stdlib.h>
 
 namespace mvd {
 
 struct WarpParams {
-    ViewPtrs src;           // V x (B,h,w,C) channel-last source features
+    ViewPtrs src;           // V x (B,h+3,w+3,C) zero-bordered channel-last source features
     ViewPtrs proj;          // V x (B,4,4) source projection matrices
-    const float* key;       // (B,h,w,C) channel-last key features (unused when WARP_ONLY)
+    const float* key;       // (B,h+3,w+3,C) zero-bordered channel-last key features (unused when WARP_ONLY)
+    const float* M;         // (V,B,12) composed transforms
     const float* key_proj_inv;  // (B,4,4)
     const float* depth;     // (B,D)
     float* out;
     int B, D, h, w, V;
     int layout;             // MVD_LAYOUT_*
+    int tiles_x, tiles_per_xcd;  // filled by launch_warp
 };
 
-// row i of (src_proj @ key_proj_inv)[:3,:4] as an fmaf chain over k (what a K=4 sgemm does)
-__device__ __forceinline__ void transform_rows(const float* __restrict__ P, const float* __restrict__ Q, float M[12]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float acc = P[i * 4 + 0] * Q[0 * 4 + j];
-            acc = fmaf(P[i * 4 + 1], Q[1 * 4 + j], acc);
-            acc = fmaf(P[i * 4 + 2], Q[2 * 4 + j], acc);
-            acc = fmaf(P[i * 4 + 3], Q[3 * 4 + j], acc);
-            M[i * 4 + j] = acc;
-        }
+// M[v][b] = (src_proj[v][b] @ key_proj_inv[b])[:3,:4] as an fmaf chain over k (what a K=4 sgemm does):
+// computed once per call by a one-block prologue kernel; the main kernel reads the 12 floats through the
+// scalar cache instead of redoing a uniform 4x4 product in every lane.
+__global__ void compose_transforms_kernel(ViewPtrs proj, const float* __restrict__ key_proj_inv, int B, int V,
+                                          float* __restrict__ M) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= V * B * 12) return;
+    const int j = e % 4, i = (e / 4) % 3, b = (e / 12) % B, v = e / (12 * B);
+    const float* P = proj.p[v] + b * 16;
+    const float* Q = key_proj_inv + b * 16;
+    float acc = P[i * 4 + 0] * Q[0 * 4 + j];
+    acc = fmaf(P[i * 4 + 1], Q[1 * 4 + j], acc);
+    acc = fmaf(P[i * 4 + 2], Q[2 * 4 + j], acc);
+    acc = fmaf(P[i * 4 + 3], Q[3 * 4 + j], acc);
+    M[e] = acc;
 }
 
-template <int LPP, bool WARP_ONLY>
-__global__ void __launch_bounds__(256) warp_variance_kernel(WarpParams p) {
+// (N, C, h, w) -> channel-last with a zero border: (N, h+3, w+3, C), pixel (y, x) at padded (y+1, x+1).
+// Rows/cols -1, w and w+1 (h, h+1) stay zero (the buffer is cleared first), so a bilinear sample whose
+// position is clamped to [-1, w] x [-1, h] needs no in-bounds logic: out-of-image taps read zeros.
+__global__ void __launch_bounds__(256) repack_padded_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                            int h, int w) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const long long hw = (long long)h * w;
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k;
+        const long long pix = p0 + tx;
+        if (c < C && pix < hw) tile[ty + 8 * k][tx] = src[((long long)n * C + c) * hw + pix];
+    }
+    __syncthreads();
+    const int W2 = w + 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long pix = p0 + ty + 8 * k;
+        const int c = c0 + tx;
+        if (c < C && pix < hw) {
+            const int y = (int)(pix / w), x = (int)(pix - (long long)y * w);
+            dst[(((long long)n * (h + 3) + y + 1) * W2 + x + 1) * C + c] = tile[tx][ty + 8 * k];
+        }
+    }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Work decomposition (the part that decides where the tap gathers are served from):
+//   * a workgroup owns one row segment of PPB key pixels and DPB consecutive depth planes; for each view
+//     it computes the DPB sample positions, issues all 4*DPB gathers back to back (buffer loads: SGPR
+//     descriptor + one 32-bit offset per sample, the 4 taps at constant strides from it) and only then
+//     accumulates, so the gathers of a view overlap each other and consecutive planes touch (nearly) the
+//     same source lines;
+//   * the 1-D grid is decoded XCD-first (blocks b and b+8 share an XCD, MI355X_MICROARCH.md): each XCD
+//     owns a contiguous band of key rows for ALL planes, so its private 4 MiB L2 only ever sees the
+//     matching band of each source image (1/8 of 7 MB per view) instead of whole images per plane —
+//     with a plane-major grid every XCD streamed all V source images per plane and the gathers were
+//     served by the Infinity Cache (measured 2.8 ms at the headline shape, profiles/r01_*).
+// Placement only affects speed; results do not depend on it.
+template <int LPP, bool WARP_ONLY, int DPB, int MINW>
+__global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) {
     constexpr int PPB = 256 / LPP;  // pixels per block
     constexpr int C = LPP * 4;
-    __shared__ float stage[WARP_ONLY ? C * (PPB + 1) : C * (PPB + 1)];
+    constexpr unsigned PIX = LPP * 16;  // bytes per pixel
+    __shared__ float stage[C * (PPB + 1)];
 
     const int tid = threadIdx.x;
-    const int q = tid % LPP;    // channel quad
-    const int px = tid / LPP;   // pixel within the block
-    const int x = blockIdx.x * PPB + px;
-    const int y = blockIdx.y;
-    const int b = blockIdx.z / p.D;
-    const int d = blockIdx.z - b * p.D;
-    const int h = p.h, w = p.w;
+    const int q = tid % LPP;   // channel quad
+    const int px = tid / LPP;  // pixel within the block
+    const int h = p.h, w = p.w, D = p.D;
+
+    // ---- decode the block index: xcd | (d-chunk fastest, then tile within the XCD's band, then batch) ----
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int dchunks = (D + DPB - 1) / DPB;
+    const int dc = j % dchunks; j /= dchunks;
+    const int tile_in = j % p.tiles_per_xcd;
+    const int b = j / p.tiles_per_xcd;
+    const int tile = xcd * p.tiles_per_xcd + tile_in;
+    if (tile >= p.tiles_x * h) return;  // block-uniform
+    const int y = tile / p.tiles_x;
+    const int x0 = (tile - y * p.tiles_x) * PPB;
+    const int x = x0 + px;
+    const int d0 = dc * DPB;
     const bool active = x < w;
     const int xc = active ? x : w - 1;
 
-    const float depth = p.depth[b * p.D + d];
-    const float gx = (float)xc * depth, gy = (float)y * depth;  // ref_grid * depth_values (utils.py:246)
-    const float fw = (float)w, fh = (float)h;
-    const float half_w = (float)(w - 1) / 2.0f, half_h = (float)(h - 1) / 2.0f;
+    // sample index = (X/Z) * w/(w-1) - 0.5: homo_warp's normalisation /((W-1)/2) - 1 followed by
+    // grid_sample's ((g+1)*W-1)/2 (utils.py:256-264), folded, with 1/Z from v_rcp_f32 (1 ulp).  Path B has
+    // no in-bounds mask, so the few-ulp difference moves a sample by < 1e-4 px and the output continuously.
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float fx = (float)xc, fy = (float)y;
+    const float xhi = (float)w, yhi = (float)h;
+    const int W2 = w + 3;
+    const unsigned rowb = (unsigned)W2 * PIX;                    // bytes per padded row
+    const unsigned img_bytes = (unsigned)(h + 3) * rowb;         // bytes per padded image
+    const unsigned org = rowb + PIX + (unsigned)q * 16;          // padded (1,1) + this lane's channel quad
 
-    float4 s1, s2;
+    float4 s1[DPB], s2[DPB];
     if constexpr (!WARP_ONLY) {
-        const float4 k = *reinterpret_cast<const float4*>(p.key + (((size_t)b * h + y) * w + xc) * C + q * 4);
-        s1 = k;
-        s2 = make_float4(k.x * k.x, k.y * k.y, k.z * k.z, k.w * k.w);
+        const float4 k = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.key) + (size_t)b * img_bytes +
+                                                          org + (unsigned)y * rowb + (unsigned)xc * PIX);
+        const float4 k2 = make_float4(k.x * k.x, k.y * k.y, k.z * k.z, k.w * k.w);
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) { s1[i] = k; s2[i] = k2; }
     } else {
-        s1 = make_float4(0, 0, 0, 0);
-        s2 = s1;
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) { s1[i] = make_float4(0, 0, 0, 0); s2[i] = s1[i]; }
     }
+    const float* __restrict__ dvals = p.depth + (size_t)b * D;
+    float dep[DPB];
+#pragma unroll
+    for (int i = 0; i < DPB; ++i) dep[i] = dvals[min(d0 + i, D - 1)];
 
     for (int v = 0; v < p.V; ++v) {
-        float M[12];
-        transform_rows(p.proj.p[v] + b * 16, p.key_proj_inv + b * 16, M);
-        // R @ (x*d, y*d, d) + T, then perspective divide (utils.py:249-252)
-        const float X = fmaf(M[2], depth, fmaf(M[1], gy, M[0] * gx)) + M[3];
-        const float Y = fmaf(M[6], depth, fmaf(M[5], gy, M[4] * gx)) + M[7];
-        const float Z = fmaf(M[10], depth, fmaf(M[9], gy, M[8] * gx)) + M[11];
-        const float nx = (X / Z) / half_w - 1.0f;  // utils.py:256-257
-        const float ny = (Y / Z) / half_h - 1.0f;
-        const Taps t = bilinear_taps(unnormalize_coord(nx, fw), unnormalize_coord(ny, fh), h, w);
-        const float* base = p.src.p[v] + (size_t)b * h * w * C + q * 4;
-        float4 acc = make_float4(0, 0, 0, 0);
+        const float* __restrict__ M = p.M + ((size_t)v * p.B + b) * 12;  // wave-uniform: scalar loads
+        // (X,Y,Z)(d) = R (x,y,1)^T d + T  (utils.py:246-250)
+        const float ax = fmaf(M[0], fx, fmaf(M[1], fy, M[2]));
+        const float ay = fmaf(M[4], fx, fmaf(M[5], fy, M[6]));
+        const float az = fmaf(M[8], fx, fmaf(M[9], fy, M[10]));
+        const float tx = M[3], ty = M[7], tz = M[11];
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.src.p[v]) + (size_t)b * img_bytes), 0, (int)img_bytes,
+            0x00020000);
+        unsigned off[DPB];
+        float wx[DPB], wy[DPB];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 f = *reinterpret_cast<const float4*>(base + (size_t)t.off[k] * C);
-            acc.x = fmaf(f.x, t.w[k], acc.x);
-            acc.y = fmaf(f.y, t.w[k], acc.y);
-            acc.z = fmaf(f.z, t.w[k], acc.z);
-            acc.w = fmaf(f.w, t.w[k], acc.w);
+        for (int i = 0; i < DPB; ++i) {
+            const float X = fmaf(ax, dep[i], tx), Y = fmaf(ay, dep[i], ty), Z = fmaf(az, dep[i], tz);
+            const float rz = __builtin_amdgcn_rcpf(Z);
+            // clamp into the zero border: a sample outside the image lands on zero taps; NaN (Z == 0) clamps to -1
+            const float ix = fminf(fmaxf(fmaf(X * rz, sx, -0.5f), -1.0f), xhi);
+            const float iy = fminf(fmaxf(fmaf(Y * rz, sy, -0.5f), -1.0f), yhi);
+            const float xf = floorf(ix), yf = floorf(iy);
+            wx[i] = ix - xf;
+            wy[i] = iy - yf;
+            off[i] = org + (unsigned)((int)yf * W2 + (int)xf) * PIX;  // (yf+1, xf+1) in the padded image
         }
-        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
-        s2.x = fmaf(acc.x, acc.x, s2.x); s2.y = fmaf(acc.y, acc.y, s2.y);
-        s2.z = fmaf(acc.z, acc.z, s2.z); s2.w = fmaf(acc.w, acc.w, s2.w);
+        u32x4 f[DPB][4];
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) {
+            f[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
+            f[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + PIX, 0, 0);
+            f[i][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb, 0, 0);
+            f[i][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb + PIX, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) {
+            const float ux = 1.0f - wx[i], uy = 1.0f - wy[i];
+            const float wt[4] = {ux * uy, wx[i] * uy, ux * wy[i], wx[i] * wy[i]};
+            float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc.x = fmaf(__uint_as_float(f[i][k].x), wt[k], acc.x);
+                acc.y = fmaf(__uint_as_float(f[i][k].y), wt[k], acc.y);
+                acc.z = fmaf(__uint_as_float(f[i][k].z), wt[k], acc.z);
+                acc.w = fmaf(__uint_as_float(f[i][k].w), wt[k], acc.w);
+            }
+            s1[i].x += acc.x; s1[i].y += acc.y; s1[i].z += acc.z; s1[i].w += acc.w;
+            s2[i].x = fmaf(acc.x, acc.x, s2[i].x); s2[i].y = fmaf(acc.y, acc.y, s2[i].y);
+            s2[i].z = fmaf(acc.z, acc.z, s2[i].z); s2[i].w = fmaf(acc.w, acc.w, s2[i].w);
+        }
     }
 
-    float4 r;
-    if constexpr (WARP_ONLY) {
-        r = s1;
-    } else {
-        const float nv = (float)(p.V + 1);  // mvsnet.py:135: sq/V - (sum/V)^2, V counting the key view
-        const float mx = s1.x / nv, my = s1.y / nv, mz = s1.z / nv, mw = s1.w / nv;
-        r = make_float4(s2.x / nv - mx * mx, s2.y / nv - my * my, s2.z / nv - mz * mz, s2.w / nv - mw * mw);
-    }
-
-    if (p.layout == MVD_LAYOUT_NDHWC) {
-        if (active)
-            *reinterpret_cast<float4*>(p.out + ((((size_t)b * p.D + d) * h + y) * w + x) * C + q * 4) = r;
-        return;
-    }
-    // NCDHW: transpose the (pixel, channel) tile through LDS so every channel row is written as
-    // PPB consecutive floats.
-    stage[(q * 4 + 0) * (PPB + 1) + px] = r.x;
-    stage[(q * 4 + 1) * (PPB + 1) + px] = r.y;
-    stage[(q * 4 + 2) * (PPB + 1) + px] = r.z;
-    stage[(q * 4 + 3) * (PPB + 1) + px] = r.w;
-    __syncthreads();
+    const float inv_nv = 1.0f / (float)(p.V + 1);  // mvsnet.py:135, V there counts the key view
     const size_t plane = (size_t)h * w;
 #pragma unroll
-    for (int i = 0; i < C * PPB / 256; ++i) {
-        const int e = tid + i * 256;
-        const int c = e / PPB, xx = e % PPB;
-        const int gxp = blockIdx.x * PPB + xx;
-        if (gxp < w)
-            p.out[(((size_t)b * C + c) * p.D + d) * plane + (size_t)y * w + gxp] = stage[c * (PPB + 1) + xx];
+    for (int i = 0; i < DPB; ++i) {
+        const int d = d0 + i;
+        if (d >= D) break;  // block-uniform
+        float4 r;
+        if constexpr (WARP_ONLY) {
+            r = s1[i];
+        } else {
+            const float mx = s1[i].x * inv_nv, my = s1[i].y * inv_nv, mz = s1[i].z * inv_nv, mw = s1[i].w * inv_nv;
+            r = make_float4(fmaf(s2[i].x, inv_nv, -mx * mx), fmaf(s2[i].y, inv_nv, -my * my),
+                            fmaf(s2[i].z, inv_nv, -mz * mz), fmaf(s2[i].w, inv_nv, -mw * mw));
+        }
+        if (p.layout == MVD_LAYOUT_NDHWC) {
+            if (active)
+                *reinterpret_cast<float4*>(p.out + ((((size_t)b * D + d) * h + y) * w + x) * C + q * 4) = r;
+            continue;
+        }
+        // NCDHW: transpose the (pixel, channel) tile through LDS so every channel row is written as
+        // PPB consecutive floats.
+        __syncthreads();
+        stage[(q * 4 + 0) * (PPB + 1) + px] = r.x;
+        stage[(q * 4 + 1) * (PPB + 1) + px] = r.y;
+        stage[(q * 4 + 2) * (PPB + 1) + px] = r.z;
+        stage[(q * 4 + 3) * (PPB + 1) + px] = r.w;
+        __syncthreads();
+#pragma unroll
+        for (int e0 = 0; e0 < C * PPB / 256; ++e0) {
+            const int e = tid + e0 * 256;
+            const int c = e / PPB, xx = e % PPB;
+            if (x0 + xx < w)
+                p.out[(((size_t)b * C + c) * D + d) * plane + (size_t)y * w + x0 + xx] = stage[c * (PPB + 1) + xx];
+        }
     }
 }
 
+// (planes per workgroup, min waves per SIMD) — tuned on MI355X; MVD_K3_CFG="dpb,minw"
+// selects another compiled variant for experiments (C = 32 only).
+static void warp_cfg(int& dpb, int& minw) {
+    dpb = 2; minw = 6;
+    if (const char* e = getenv("MVD_K3_CFG")) sscanf(e, "%d,%d", &dpb, &minw);
+}
+
+static size_t padded_image_floats(int C, int h, int w) { return (size_t)(h + 3) * (w + 3) * C; }
+static size_t padded_slot_bytes(int B, int C, int h, int w) {
+    return align_up((size_t)B * padded_image_floats(C, h, w) * sizeof(float), 256);
+}
+
+// clears the slot and writes the zero-bordered channel-last copy of one (B,C,h,w) feature map into it
+static int repack_padded(const float* src, float* dst, int B, int C, int h, int w, hipStream_t st) {
+    if (hipMemsetAsync(dst, 0, padded_slot_bytes(B, C, h, w), st) != hipSuccess) return launch_status("repack: memset");
+    const long long hw = (long long)h * w;
+    dim3 grid((unsigned)((hw + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(repack_padded_kernel, grid, dim3(256), 0, st, src, dst, C, h, w);
+    return launch_status("repack_padded");
+}
+
 template <bool WARP_ONLY>
-static int launch_warp(const WarpParams& p, int C, hipStream_t st) {
+static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
+    WarpParams p = p0;
     const int lpp = C / 4;
+    int dpb, minw;
+    warp_cfg(dpb, minw);
+    if (lpp != 8) { dpb = 4; minw = 3; }
     const int ppb = 256 / lpp;
-    dim3 grid((unsigned)((p.w + ppb - 1) / ppb), (unsigned)p.h, (unsigned)(p.B * p.D));
-    timing_begin(st);
-    switch (lpp) {
-#define MVD_CASE(L)                                                                                  \
-    case L:                                                                                          \
-        hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY>), grid, dim3(256), 0, st, p);        \
-        break;
-        MVD_CASE(1) MVD_CASE(2) MVD_CASE(4) MVD_CASE(8) MVD_CASE(16)
-#undef MVD_CASE
-        default:
-            set_error("warp_variance: C=%d unsupported (need 4, 8, 16, 32 or 64)", C);
-            return MVD_ERR_INVALID_ARG;
+    p.tiles_x = (p.w + ppb - 1) / ppb;
+    const long long tiles = (long long)p.tiles_x * p.h;
+    p.tiles_per_xcd = (int)((tiles + 7) / 8);
+    const long long nblk = 8LL * p.tiles_per_xcd * ((p.D + dpb - 1) / dpb) * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("warp_variance: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
     }
+    const dim3 grid((unsigned)nblk);
+    timing_begin(st);
+#define MVD_LAUNCH(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW>), grid, dim3(256), 0, st, p)
+    if (lpp == 8) {
+        switch (dpb * 10 + minw) {
+            case 18: MVD_LAUNCH(8, 1, 8); break;
+            case 24: MVD_LAUNCH(8, 2, 4); break;
+            case 28: MVD_LAUNCH(8, 2, 8); break;
+            case 26: MVD_LAUNCH(8, 2, 6); break;
+            case 42: MVD_LAUNCH(8, 4, 2); break;
+            case 43: MVD_LAUNCH(8, 4, 3); break;
+            case 44: MVD_LAUNCH(8, 4, 4); break;
+            case 82: MVD_LAUNCH(8, 8, 2); break;
+            case 83: MVD_LAUNCH(8, 8, 3); break;
+            default:
+                set_error("warp_variance: MVD_K3_CFG=%d,%d is not a compiled variant", dpb, minw);
+                return MVD_ERR_INVALID_ARG;
+        }
+    } else {
+        switch (lpp) {
+            case 1: MVD_LAUNCH(1, 4, 3); break;
+            case 2: MVD_LAUNCH(2, 4, 3); break;
+            case 4: MVD_LAUNCH(4, 4, 3); break;
+            case 16: MVD_LAUNCH(16, 4, 3); break;
+        }
+    }
+#undef MVD_LAUNCH
     timing_end(st);
     return launch_status("warp_variance");
 }
 
-int transpose_launch(const float* src, float* dst, int N, long long rows, long long cols, hipStream_t st);
+// shared by the two entry points: validates, lays out the workspace, repacks, composes, launches
+static int run_warp(const float* key_feat, const float* const* src_feat, const float* const* src_proj,
+                    const float* key_proj_inv, const float* depth_values, int B, int C, int D, int h, int w, int V,
+                    float* out, int layout, void* workspace, size_t workspace_bytes, hipStream_t st, bool warp_only) {
+    const char* who = warp_only ? "homo_warp" : "warp_variance";
+    MVD_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "%s: non-positive dimension (h, w must be >= 2)", who);
+    MVD_REQUIRE(V >= 1 && V <= MVD_MAX_VIEWS, "%s: V=%d outside 1..%d", who, V, MVD_MAX_VIEWS);
+    MVD_REQUIRE(C == 4 || C == 8 || C == 16 || C == 32 || C == 64, "%s: C=%d unsupported (need 4, 8, 16, 32 or 64)", who, C);
+    MVD_REQUIRE((long long)(h + 3) * (w + 3) * C * 4 < 0x7fffffffLL && h < (1 << 23) && w < (1 << 23),
+                "%s: one padded feature map of %dx%dx%d floats exceeds the 2 GiB buffer-offset range", who, h, w, C);
+    const size_t need = mvd_warp_variance_workspace_bytes(B, C, h, w, warp_only ? 0 : V);
+    if (!workspace || workspace_bytes < need) {
+        set_error("%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
+        return MVD_ERR_WORKSPACE;
+    }
+    const size_t slot = padded_slot_bytes(B, C, h, w);
+    char* ws = (char*)workspace;
+    WarpParams p{};
+    p.M = (float*)ws;
+    ws += align_up((size_t)MVD_MAX_VIEWS * B * 12 * sizeof(float), 256);
+    int rc;
+    if (!warp_only) {
+        rc = repack_padded(key_feat, (float*)ws, B, C, h, w, st);
+        if (rc) return rc;
+        p.key = (float*)ws;
+        ws += slot;
+    }
+    for (int v = 0; v < V; ++v) {
+        MVD_REQUIRE(src_feat[v] && src_proj[v], "%s: NULL view %d", who, v);
+        rc = repack_padded(src_feat[v], (float*)ws, B, C, h, w, st);
+        if (rc) return rc;
+        p.src.p[v] = (float*)ws;
+        p.proj.p[v] = src_proj[v];
+        ws += slot;
+    }
+    hipLaunchKernelGGL(compose_transforms_kernel, dim3((unsigned)((V * B * 12 + 255) / 256)), dim3(256), 0, st, p.proj,
+                       key_proj_inv, B, V, const_cast<float*>(p.M));
+    rc = launch_status("compose_transforms");
+    if (rc) return rc;
+    p.key_proj_inv = key_proj_inv;
+    p.depth = depth_values;
+    p.out = out;
+    p.B = B; p.D = D; p.h = h; p.w = w; p.V = V;
+    p.layout = layout;
+    return warp_only ? launch_warp<true>(p, C, st) : launch_warp<false>(p, C, st);
+}
 
 }  // namespace mvd
 
@@ -157,7 +353,9 @@ extern "C" {
 
 size_t mvd_warp_variance_workspace_bytes(int B, int C, int h, int w, int V) {
     if (B <= 0 || C <= 0 || h <= 0 || w <= 0 || V < 0) return 0;
-    return (size_t)(V + 1) * mvd::align_up((size_t)B * C * h * w * sizeof(float), 256);
+    // transforms + (V + 1) zero-bordered channel-last feature copies (V = 0: homo_warp, one copy)
+    return mvd::align_up((size_t)MVD_MAX_VIEWS * B * 12 * sizeof(float), 256) +
+           (size_t)(V + 1) * mvd::padded_slot_bytes(B, C, h, w);
 }
 
 int mvd_warp_variance_f32(const float* key_feat, const float* const* src_feat, const float* const* src_proj,
@@ -166,62 +364,18 @@ int mvd_warp_variance_f32(const float* key_feat, const float* const* src_feat, c
                           mvd_stream_t stream) {
     MVD_REQUIRE(key_feat && src_feat && src_proj && key_proj_inv && depth_values && var_out,
                 "warp_variance: NULL argument");
-    MVD_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "warp_variance: non-positive dimension");
-    MVD_REQUIRE(V >= 1 && V <= MVD_MAX_VIEWS, "warp_variance: V=%d outside 1..%d", V, MVD_MAX_VIEWS);
-    MVD_REQUIRE(h <= 65535 && (long long)B * D <= 65535, "warp_variance: h or B*D exceeds 65535");
     MVD_REQUIRE(out_layout == MVD_LAYOUT_NCDHW || out_layout == MVD_LAYOUT_NDHWC, "warp_variance: bad layout");
-    const size_t need = mvd_warp_variance_workspace_bytes(B, C, h, w, V);
-    if (!workspace || workspace_bytes < need) {
-        mvd::set_error("warp_variance: workspace %zu B < required %zu B", workspace_bytes, need);
-        return MVD_ERR_WORKSPACE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    const size_t per = mvd::align_up((size_t)B * C * h * w * sizeof(float), 256) / sizeof(float);
-    float* ws = (float*)workspace;
-    mvd::WarpParams p{};
-    int rc = mvd::transpose_launch(key_feat, ws, B, C, (long long)h * w, st);
-    if (rc) return rc;
-    p.key = ws;
-    for (int v = 0; v < V; ++v) {
-        MVD_REQUIRE(src_feat[v] && src_proj[v], "warp_variance: NULL view %d", v);
-        float* dst = ws + (size_t)(v + 1) * per;
-        rc = mvd::transpose_launch(src_feat[v], dst, B, C, (long long)h * w, st);
-        if (rc) return rc;
-        p.src.p[v] = dst;
-        p.proj.p[v] = src_proj[v];
-    }
-    p.key_proj_inv = key_proj_inv;
-    p.depth = depth_values;
-    p.out = var_out;
-    p.B = B; p.D = D; p.h = h; p.w = w; p.V = V;
-    p.layout = out_layout;
-    return mvd::launch_warp<false>(p, C, st);
+    return mvd::run_warp(key_feat, src_feat, src_proj, key_proj_inv, depth_values, B, C, D, h, w, V, var_out, out_layout,
+                         workspace, workspace_bytes, (hipStream_t)stream, false);
 }
 
 int mvd_homo_warp_f32(const float* src_feat, const float* src_proj, const float* key_proj_inv,
                       const float* depth_values, int B, int C, int D, int h, int w, float* warped_out,
                       void* workspace, size_t workspace_bytes, mvd_stream_t stream) {
     MVD_REQUIRE(src_feat && src_proj && key_proj_inv && depth_values && warped_out, "homo_warp: NULL argument");
-    MVD_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "homo_warp: non-positive dimension");
-    MVD_REQUIRE(h <= 65535 && (long long)B * D <= 65535, "homo_warp: h or B*D exceeds 65535");
-    const size_t need = mvd_warp_variance_workspace_bytes(B, C, h, w, 0);
-    if (!workspace || workspace_bytes < need) {
-        mvd::set_error("homo_warp: workspace %zu B < required %zu B", workspace_bytes, need);
-        return MVD_ERR_WORKSPACE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    float* ws = (float*)workspace;
-    int rc = mvd::transpose_launch(src_feat, ws, B, C, (long long)h * w, st);
-    if (rc) return rc;
-    mvd::WarpParams p{};
-    p.src.p[0] = ws;
-    p.proj.p[0] = src_proj;
-    p.key = nullptr;
-    p.key_proj_inv = key_proj_inv;
-    p.depth = depth_values;
-    p.out = warped_out;
-    p.B = B; p.D = D; p.h = h; p.w = w; p.V = 1;
-    p.layout = MVD_LAYOUT_NCDHW;
-    return mvd::launch_warp<true>(p, C, st);
+    const float* srcs[1] = {src_feat};
+    const float* projs[1] = {src_proj};
+    return mvd::run_warp(nullptr, srcs, projs, key_proj_inv, depth_values, B, C, D, h, w, 1, warped_out,
+                         MVD_LAYOUT_NCDHW, workspace, workspace_bytes, (hipStream_t)stream, true);
 }
 }
