@@ -69,28 +69,18 @@ def adapted_sample(model, frame_idx, H, W, V, depth_range=None):
 def timed_loop(model, samples, steps, warmup, world, dev, arm=None):
     """W untimed + K timed forwards bracketed by barrier + synchronize; returns seconds (max over ranks)."""
     import torch.distributed as dist
-    with torch.no_grad():
-        for i in range(warmup):
-            model(**samples[i % len(samples)])
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            if arm is not None:
-                arm(i)
-            model(**samples[i % len(samples)])
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    from robustmvd_amd.sharding import timed_region
+
+    def run(n, armed):
+        with torch.no_grad():
+            for i in range(n):
+                if armed and arm is not None:
+                    arm(i)
+                model(**samples[i % len(samples)])
+
+    run(warmup, False)
+    return timed_region(lambda: run(steps, True), sync=lambda: torch.cuda.synchronize(dev),
+                        dist=dist if world > 1 else None, device=dev)
 
 
 def measured_copy_gbs(dev):
@@ -158,7 +148,9 @@ def main():
     model, sd = build_mvsnet(D, dev)
     # this rank's frames: frame index = rank + world * i (round-robin shard of the frame list)
     nframes = 2
-    samples = [adapted_sample(model, rank + world * i, H, W, V, (np.float32(0.5), np.float32(10.0))) for i in range(nframes)]
+    from robustmvd_amd.sharding import frames_for_rank
+    my_frames = frames_for_rank(nframes * world, rank, world)
+    samples = [adapted_sample(model, f, H, W, V, (np.float32(0.5), np.float32(10.0))) for f in my_frames]
 
     # HIP events around every warp+variance launch inside the timed region
     from robustmvd_amd import _lib as L
@@ -202,7 +194,7 @@ def main():
     if not args.no_path_a and args.config in (1, 2, 3):
         # robust_mvd (Path A, the create_model("robust_mvd") drop-in) at the same image shape; S = 256 planes fixed
         ma, _ = build_robustmvd(dev)
-        sa = [adapted_sample(ma, rank + world * i, H, W, V) for i in range(nframes)]
+        sa = [adapted_sample(ma, f, H, W, V) for f in my_frames]
         eva = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         for a, b in eva:
             a.record(); b.record()

@@ -15,7 +15,15 @@
 // that tile the channel-last output contiguously.
 //
 // Workgroup = 4 waves; wave r owns output row r of a TH=4 x TW=16*MT tile of one output depth plane
-// (for the transposed conv: of one output parity class, which turns it into 8 small dense convs).
+// (for the transposed conv: of one output (d,h)-parity class and BOTH w-parities, which turns it into
+// small dense convs whose results interleave into full contiguous output rows).
+//
+// Cout = 8 (conv0, the layer that carries 2/3 of the regulariser's FLOPs) would leave half of the 16 MFMA
+// rows empty.  Its stride-1 form is therefore run in PAIR mode: the 16 rows are (w-phase j in {0,1}) x
+// (8 couts) and the columns are PAIRS of adjacent output voxels, i.e. a stride-2-in-w convolution with a
+// 4-tap kernel W'[j][t] = W[t-j] (zero outside 0..2): 4/3 of the taps but twice the useful rows, 1.5x
+// fewer MFMAs for the same result (each product that is kept is bit-identical; the extra ones multiply by 0).
+// Cout = 1 (the final `prob` layer) would use 1 row of 16: it has its own vector-ALU kernel below.
 #include "mvd_common.h"
 
 namespace mvd {
@@ -48,15 +56,17 @@ struct KGroup {
 
 // packed weight index: [tap 27][k-group][n-tile][lane 64][R]
 template <int CIN>
-__host__ __device__ constexpr size_t packed_floats(int nt) {
-    return (size_t)27 * KGroup<CIN>::NKG * nt * 64 * KGroup<CIN>::R;
+__host__ __device__ constexpr size_t packed_floats(int nt, int taps = 27) {
+    return (size_t)taps * KGroup<CIN>::NKG * nt * 64 * KGroup<CIN>::R;
 }
+constexpr int MVD_CONV3D_S1_PAIR = 3;  // internal mode: stride-1 conv with Cout == 8 (see header)
 
 template <int CIN>
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int NT,
                                     int transposed) {
     using G = KGroup<CIN>;
-    const size_t total = packed_floats<CIN>(NT);
+    const bool pair = transposed == 2;  // PAIR mode: taps = (kd, kh, t in 0..3), row = phase * 8 + cout
+    const size_t total = packed_floats<CIN>(NT, pair ? 36 : 27);
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         size_t r = e;
         const int j = r % G::R; r /= G::R;
@@ -64,24 +74,41 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int nt = r % NT; r /= NT;
         const int g = r % G::NKG; r /= G::NKG;
         const int tap = (int)r;
-        const int cout = nt * 16 + (lane & 15);
+        const int row = nt * 16 + (lane & 15);
         const int cin = g * G::KG + G::R * (lane >> 4) + j;
         float val = 0.f;
-        if (cout < Cout)
-            val = transposed ? w[((size_t)cin * Cout + cout) * 27 + tap]   // ConvTranspose3d: (Cin,Cout,3,3,3)
-                             : w[((size_t)cout * CIN + cin) * 27 + tap];   // Conv3d: (Cout,Cin,3,3,3)
+        if (pair) {
+            const int phase = row >> 3, cout = row & 7;
+            const int t = tap & 3, kdh = tap >> 2;  // kdh = kd * 3 + kh
+            const int kw = t - phase;
+            if (kw >= 0 && kw <= 2) val = w[((size_t)cout * CIN + cin) * 27 + kdh * 3 + kw];
+        } else if (row < Cout) {
+            val = transposed ? w[((size_t)cin * Cout + row) * 27 + tap]   // ConvTranspose3d: (Cin,Cout,3,3,3)
+                             : w[((size_t)row * CIN + cin) * 27 + tap];   // Conv3d: (Cout,Cin,3,3,3)
+        }
         packed[e] = val;
     }
 }
 
-// MODE: MVD_CONV3D_STRIDE1 / MVD_CONV3D_STRIDE2 / MVD_DECONV3D_STRIDE2
+// geometry of one workgroup tile per mode
+template <int MODE, int MT>
+struct TileGeom {
+    static constexpr bool S2 = MODE == MVD_CONV3D_STRIDE2, DECONV = MODE == MVD_DECONV3D_STRIDE2, PAIR = MODE == MVD_CONV3D_S1_PAIR;
+    static constexpr int TW = 16 * MT;  // GEMM columns per wave row: output voxels (S1/S2), voxel pairs (PAIR), input cols (DECONV)
+    static constexpr int SX = (S2 || PAIR) ? 2 : 1;  // slab columns per GEMM column
+    static constexpr int ROWS = S2 ? 2 * CONV_TH + 1 : DECONV ? CONV_TH + 1 : CONV_TH + 2;
+    static constexpr int COLS = S2 ? 2 * TW + 1 : DECONV ? TW + 1 : PAIR ? 2 * TW + 2 : TW + 2;
+    static constexpr int NPW = DECONV ? 2 : 1;       // output w-parity classes accumulated together
+    static constexpr int NWT = DECONV ? 3 : PAIR ? 4 : 3;  // w-tap list length
+};
+
+// MODE: MVD_CONV3D_STRIDE1 / MVD_CONV3D_STRIDE2 / MVD_DECONV3D_STRIDE2 / MVD_CONV3D_S1_PAIR
 template <int CIN, int NT, int MT, int MODE>
 __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
     using G = KGroup<CIN>;
-    constexpr int TW = 16 * MT;
-    constexpr int SX = (MODE == MVD_CONV3D_STRIDE2) ? 2 : 1;  // input step per output voxel
-    constexpr int ROWS = MODE == MVD_CONV3D_STRIDE1 ? CONV_TH + 2 : MODE == MVD_CONV3D_STRIDE2 ? 2 * CONV_TH + 1 : CONV_TH + 1;
-    constexpr int COLS = MODE == MVD_CONV3D_STRIDE1 ? TW + 2 : MODE == MVD_CONV3D_STRIDE2 ? 2 * TW + 1 : TW + 1;
+    using T = TileGeom<MODE, MT>;
+    constexpr bool S2 = T::S2, DECONV = T::DECONV, PAIR = T::PAIR;
+    constexpr int TW = T::TW, SX = T::SX, ROWS = T::ROWS, COLS = T::COLS, NPW = T::NPW;
     constexpr int PSTR = CIN + CONV_PAD;  // floats per LDS pixel
     extern __shared__ __attribute__((aligned(16))) float slab[];  // [ROWS][COLS][PSTR]
 
@@ -93,85 +120,80 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
     int bx = blockIdx.x;
     const int tw = bx % p.tiles_w; bx /= p.tiles_w;
     const int th = bx % p.tiles_h; bx /= p.tiles_h;
-    int par = 0;  // output parity class (deconv only): bit2 = d, bit1 = h, bit0 = w
-    if constexpr (MODE == MVD_DECONV3D_STRIDE2) { par = bx & 7; bx >>= 3; }
-    const int pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
+    int pd = 0, ph = 0;  // output (d, h) parity class (deconv only)
+    if constexpr (DECONV) { pd = (bx >> 1) & 1; ph = bx & 1; bx >>= 2; }
     // grid z-extent: output depth planes (conv) or input depth planes (deconv, one per parity class)
-    const int nzd = MODE == MVD_DECONV3D_STRIDE2 ? p.Di : p.Do;
+    const int nzd = DECONV ? p.Di : p.Do;
     const int zd = bx % nzd;
     const int b = bx / nzd;
-    const int r0 = th * CONV_TH;  // first tile row (output rows for conv, input rows a0 for deconv)
-    const int c0 = tw * TW;
+    const int r0 = th * CONV_TH;  // first tile row (output rows for conv, input rows for deconv)
+    const int c0 = tw * TW;       // first GEMM column of the tile
 
     // input-plane list: conv: kd = 0..2 -> plane SZ*zd + kd - 1; deconv: pd=0: (k=1, plane zd); pd=1: (k=0, zd+1), (k=2, zd)
-    constexpr int SZ = (MODE == MVD_CONV3D_STRIDE2) ? 2 : 1;
-    const int nplanes = MODE == MVD_DECONV3D_STRIDE2 ? (pd ? 2 : 1) : 3;
+    constexpr int SZ = S2 ? 2 : 1;
+    const int nplanes = DECONV ? (pd ? 2 : 1) : 3;
     // first input row / col held by the slab
-    const int in_r0 = MODE == MVD_CONV3D_STRIDE1 ? r0 - 1 : MODE == MVD_CONV3D_STRIDE2 ? 2 * r0 - 1 : r0;
-    const int in_c0 = MODE == MVD_CONV3D_STRIDE1 ? c0 - 1 : MODE == MVD_CONV3D_STRIDE2 ? 2 * c0 - 1 : c0;
+    const int in_r0 = S2 ? 2 * r0 - 1 : DECONV ? r0 : r0 - 1;
+    const int in_c0 = S2 ? 2 * c0 - 1 : DECONV ? c0 : PAIR ? 2 * c0 - 1 : c0 - 1;
 
-    f32x4 acc[MT][NT];
+    f32x4 acc[NPW][MT][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int c = 0; c < NPW; ++c)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const float4* __restrict__ wpk4 = reinterpret_cast<const float4*>(p.wpk);
-    (void)wpk4;
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[c][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int ip = 0; ip < nplanes; ++ip) {
         int kd, plane;
-        if constexpr (MODE == MVD_DECONV3D_STRIDE2) {
+        if constexpr (DECONV) {
             kd = pd ? (ip == 0 ? 0 : 2) : 1;
             plane = pd ? (ip == 0 ? zd + 1 : zd) : zd;
         } else {
             kd = ip;
             plane = SZ * zd + ip - 1;
         }
-        const bool plane_ok = plane >= 0 && plane < p.Di;  // block-uniform
-        if (!plane_ok) continue;                            // contributes zeros
+        if (plane < 0 || plane >= p.Di) continue;  // block-uniform; contributes zeros
 
         __syncthreads();  // previous plane's reads are done
-        // ---- stage the input rows of this plane (zero-filled halo) ----------------------------
+        // ---- stage the input rows of this plane (zero-filled halo): one wave per row, 1 KB per pass ----
         {
             constexpr int C4 = CIN / 4;
-            constexpr int NV = ROWS * COLS * C4;
             const float* __restrict__ xp = p.x + ((size_t)b * p.Di + plane) * p.hi * p.wi * CIN;
-            for (int e = tid; e < NV; e += 256) {
-                const int c4 = e % C4;
-                const int col = (e / C4) % COLS;
-                const int row = e / (C4 * COLS);
-                const int gr = in_r0 + row, gc = in_c0 + col;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gr >= 0 && gr < p.hi && gc >= 0 && gc < p.wi)
-                    v = *reinterpret_cast<const float4*>(xp + ((size_t)gr * p.wi + gc) * CIN + c4 * 4);
-                *reinterpret_cast<float4*>(slab + (row * COLS + col) * PSTR + c4 * 4) = v;
+            for (int row = wave; row < ROWS; row += 4) {
+                const int gr = in_r0 + row;
+                const bool row_ok = gr >= 0 && gr < p.hi;
+                const float* __restrict__ xr = xp + (size_t)(row_ok ? gr : 0) * p.wi * CIN;
+                for (int e = lane; e < COLS * C4; e += 64) {
+                    const int col = e / C4, c4 = e % C4;
+                    const int gc = in_c0 + col;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row_ok && gc >= 0 && gc < p.wi) v = *reinterpret_cast<const float4*>(xr + (size_t)gc * CIN + c4 * 4);
+                    *reinterpret_cast<float4*>(slab + (row * COLS + col) * PSTR + c4 * 4) = v;
+                }
             }
         }
         __syncthreads();
 
         // ---- taps of this plane ----------------------------------------------------------------
-        const int nkh = MODE == MVD_DECONV3D_STRIDE2 ? (ph ? 2 : 1) : 3;
-        const int nkw = MODE == MVD_DECONV3D_STRIDE2 ? (pw ? 2 : 1) : 3;
+        const int nkh = DECONV ? (ph ? 2 : 1) : 3;
         for (int ih = 0; ih < nkh; ++ih) {
             int kh, srow;  // kernel index, slab row read by this wave
-            if constexpr (MODE == MVD_DECONV3D_STRIDE2) {
+            if constexpr (DECONV) {
                 kh = ph ? (ih == 0 ? 0 : 2) : 1;
                 srow = wave + (ph ? (ih == 0 ? 1 : 0) : 0);
             } else {
                 kh = ih;
-                srow = SX * wave + ih;
+                srow = (S2 ? 2 : 1) * wave + ih;
             }
-            for (int iw = 0; iw < nkw; ++iw) {
-                int kw, scol;  // kernel index, slab column of output voxel 0 of the tile
-                if constexpr (MODE == MVD_DECONV3D_STRIDE2) {
-                    kw = pw ? (iw == 0 ? 0 : 2) : 1;
-                    scol = pw ? (iw == 0 ? 1 : 0) : 0;
-                } else {
-                    kw = iw;
-                    scol = iw;
-                }
-                const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+            for (int iw = 0; iw < T::NWT; ++iw) {
+                // (kernel w index or pair tap, slab column of GEMM column 0, output w-parity class)
+                constexpr int dkw[3] = {1, 0, 2}, dsc[3] = {0, 1, 0}, dcl[3] = {0, 1, 1};
+                const int kw = DECONV ? dkw[iw % 3] : iw;
+                const int scol = DECONV ? dsc[iw % 3] : iw;
+                const int cls = DECONV ? dcl[iw % 3] : 0;
+                const int tap = PAIR ? (kd * 3 + kh) * 4 + kw : (kd * 3 + kh) * 3 + kw;
                 const float* __restrict__ srow_p = slab + (srow * COLS + scol) * PSTR + G::R * q;
 #pragma unroll
                 for (int g = 0; g < G::NKG; ++g) {
@@ -188,88 +210,145 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
                             af[n][0] = t.x; af[n][1] = t.y;
                         }
                     }
+                    // B fragments (activations) for all column tiles first, then the MFMAs round-robin over the
+                    // accumulators (a 16x16x4 f32 MFMA has a 40-cycle dependent latency but issues every 32)
+                    float bf[MT][G::R];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const float* bp = srow_p + ((m * 16 + vox) * SX) * PSTR + g * G::KG;
-                        float bf[G::R];
                         if constexpr (G::R == 4) {
                             const float4 t = *reinterpret_cast<const float4*>(bp);
-                            bf[0] = t.x; bf[1] = t.y; bf[2] = t.z; bf[3] = t.w;
+                            bf[m][0] = t.x; bf[m][1] = t.y; bf[m][2] = t.z; bf[m][3] = t.w;
                         } else {
                             const float2 t = *reinterpret_cast<const float2*>(bp);
-                            bf[0] = t.x; bf[1] = t.y;
+                            bf[m][0] = t.x; bf[m][1] = t.y;
                         }
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-#pragma unroll
-                            for (int j = 0; j < G::R; ++j)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n][j], bf[j], acc[m][n], 0, 0, 0);
                     }
+#pragma unroll
+                    for (int j = 0; j < G::R; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) {
+                                if constexpr (NPW == 2) {
+                                    if (cls == 0)
+                                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n][j], bf[m][j], acc[0][m][n], 0, 0, 0);
+                                    else
+                                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n][j], bf[m][j], acc[1][m][n], 0, 0, 0);
+                                } else {
+                                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n][j], bf[m][j], acc[0][m][n], 0, 0, 0);
+                                }
+                            }
                 }
             }
         }
     }
 
-    // ---- epilogue: y = act(acc*scale + shift) (+ skip); lane holds couts 16n + 4q .. +3 of voxel `vox` ----
-    int orow, ocol_step, ocol0, oz;
-    if constexpr (MODE == MVD_DECONV3D_STRIDE2) {
-        orow = 2 * (r0 + wave) + ph;
-        ocol0 = 2 * c0 + pw;
-        ocol_step = 2;
-        oz = 2 * zd + pd;
-    } else {
-        orow = r0 + wave;
-        ocol0 = c0;
-        ocol_step = 1;
-        oz = zd;
-    }
+    // ---- epilogue: y = act(acc*scale + shift) (+ skip); lane holds rows 16n + 4q .. +3 of GEMM column `vox` ----
+    const int orow = DECONV ? 2 * (r0 + wave) + ph : r0 + wave;
+    const int oz = DECONV ? 2 * zd + pd : zd;
     if (orow >= p.ho) return;
     const size_t row_base = (((size_t)b * p.Do + oz) * p.ho + orow) * p.wo;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int ocol = ocol0 + (m * 16 + vox) * ocol_step;
-        if (ocol >= p.wo) continue;
-        const size_t o = (row_base + ocol) * p.Cout;
+    for (int c = 0; c < NPW; ++c)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int cb = n * 16 + q * 4;
-            if (cb >= p.Cout) continue;
-            float r[4];
+        for (int m = 0; m < MT; ++m) {
+            const int gcol = c0 + m * 16 + vox;
+            const int ocol = DECONV ? 2 * gcol + c : PAIR ? 2 * gcol + (q >> 1) : gcol;
+            if (ocol >= p.wo) continue;
+            const size_t o = (row_base + ocol) * p.Cout;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = cb + k;
-                float val = 0.f;
-                if (c < p.Cout) {
-                    val = fmaf(acc[m][n][k], p.scale[c], p.shift[c]);
-                    if (p.relu) val = fmaxf(val, 0.f);
-                    if (p.skip) val += p.skip[o + c];
+            for (int n = 0; n < NT; ++n) {
+                const int cb = PAIR ? 4 * (q & 1) : n * 16 + q * 4;  // first of this lane's 4 output channels
+                if (cb >= p.Cout) continue;
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ch = cb + k;
+                    float val = 0.f;
+                    if (ch < p.Cout) {
+                        val = fmaf(acc[c][m][n][k], p.scale[ch], p.shift[ch]);
+                        if (p.relu) val = fmaxf(val, 0.f);
+                        if (p.skip) val += p.skip[o + ch];
+                    }
+                    r[k] = val;
                 }
-                r[k] = val;
-            }
-            if (cb + 3 < p.Cout) {
-                *reinterpret_cast<float4*>(p.y + o + cb) = make_float4(r[0], r[1], r[2], r[3]);
-            } else {
-                for (int k = 0; k < 4; ++k)
-                    if (cb + k < p.Cout) p.y[o + cb + k] = r[k];
+                if (cb + 3 < p.Cout) {
+                    *reinterpret_cast<float4*>(p.y + o + cb) = make_float4(r[0], r[1], r[2], r[3]);
+                } else {
+                    for (int k = 0; k < 4; ++k)
+                        if (cb + k < p.Cout) p.y[o + cb + k] = r[k];
+                }
             }
         }
+}
+
+// `prob`: 3x3x3, 8 -> 1 channels, stride 1 (mvsnet_components.py:109).  One GEMM row of 16 would be used on
+// the matrix cores, so this layer runs on the vector ALU: one lane per output voxel, the three input planes
+// of a 4 x 64 tile resident in LDS (48-B pixels: conflict-free ds_read_b128 across consecutive columns), the
+// 216 weights through the scalar cache.  packed weights here are [tap 27][cin 8].
+__global__ void __launch_bounds__(256) conv3d_c8_to_1_kernel(ConvParams p) {
+    constexpr int CIN = 8, TW = 64, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN + CONV_PAD;
+    __shared__ __attribute__((aligned(16))) float slab[3 * ROWS * COLS * PSTR];  // 57 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx = blockIdx.x;
+    const int tw = bx % p.tiles_w; bx /= p.tiles_w;
+    const int th = bx % p.tiles_h; bx /= p.tiles_h;
+    const int zd = bx % p.Do;
+    const int b = bx / p.Do;
+    const int r0 = th * CONV_TH, c0 = tw * TW;
+    for (int r = wave; r < 3 * ROWS; r += 4) {
+        const int kd = r / ROWS, row = r - kd * ROWS;
+        const int plane = zd + kd - 1, gr = r0 - 1 + row;
+        const bool ok = plane >= 0 && plane < p.Di && gr >= 0 && gr < p.hi;
+        const float* __restrict__ xr = p.x + (((size_t)b * p.Di + (ok ? plane : 0)) * p.hi + (ok ? gr : 0)) * p.wi * CIN;
+        for (int e = lane; e < COLS * 2; e += 64) {
+            const int col = e >> 1, c4 = e & 1, gc = c0 - 1 + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && gc >= 0 && gc < p.wi) v = *reinterpret_cast<const float4*>(xr + (size_t)gc * CIN + c4 * 4);
+            *reinterpret_cast<float4*>(slab + (r * COLS + col) * PSTR + c4 * 4) = v;
+        }
     }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* sp = slab + ((kd * ROWS + wave + kh) * COLS + lane + kw) * PSTR;
+                const float4 a = *reinterpret_cast<const float4*>(sp), c = *reinterpret_cast<const float4*>(sp + 4);
+                const float* __restrict__ wv = p.wpk + ((kd * 3 + kh) * 3 + kw) * 8;  // uniform: s_load
+                acc = fmaf(a.x, wv[0], acc); acc = fmaf(a.y, wv[1], acc); acc = fmaf(a.z, wv[2], acc); acc = fmaf(a.w, wv[3], acc);
+                acc = fmaf(c.x, wv[4], acc); acc = fmaf(c.y, wv[5], acc); acc = fmaf(c.z, wv[6], acc); acc = fmaf(c.w, wv[7], acc);
+            }
+    const int orow = r0 + wave, ocol = c0 + lane;
+    if (orow >= p.ho || ocol >= p.wo) return;
+    const size_t o = (((size_t)b * p.Do + zd) * p.ho + orow) * p.wo + ocol;
+    float val = fmaf(acc, p.scale[0], p.shift[0]);
+    if (p.relu) val = fmaxf(val, 0.f);
+    if (p.skip) val += p.skip[o];
+    p.y[o] = val;
+}
+
+__global__ void pack_c8_to_1_kernel(const float* __restrict__ w, float* __restrict__ packed) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // packed [tap][cin] <- w (1, 8, 27)
+    if (e < 216) packed[e] = w[(e % 8) * 27 + e / 8];
 }
 
 template <int CIN, int NT, int MT, int MODE>
 static int launch_conv(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
-    constexpr int TW = 16 * MT;
-    constexpr int ROWS = MODE == MVD_CONV3D_STRIDE1 ? CONV_TH + 2 : MODE == MVD_CONV3D_STRIDE2 ? 2 * CONV_TH + 1 : CONV_TH + 1;
-    constexpr int COLS = MODE == MVD_CONV3D_STRIDE1 ? TW + 2 : MODE == MVD_CONV3D_STRIDE2 ? 2 * TW + 1 : TW + 1;
-    constexpr size_t lds = (size_t)ROWS * COLS * (CIN + CONV_PAD) * sizeof(float);
+    using T = TileGeom<MODE, MT>;
+    constexpr size_t lds = (size_t)T::ROWS * T::COLS * (CIN + CONV_PAD) * sizeof(float);
     static_assert(lds <= 160 * 1024, "slab exceeds LDS");
-    // tiles over the output grid (conv) or over the input grid = one parity class of the output (deconv)
-    const int gh = MODE == MVD_DECONV3D_STRIDE2 ? p.hi : p.ho;
-    const int gw = MODE == MVD_DECONV3D_STRIDE2 ? p.wi : p.wo;
+    // tiles over the GEMM-column grid: output voxels (conv), voxel pairs (PAIR) or input voxels (deconv)
+    const int gh = T::DECONV ? p.hi : p.ho;
+    const int gw = T::DECONV ? p.wi : T::PAIR ? (p.wo + 1) / 2 : p.wo;
     p.tiles_h = (gh + CONV_TH - 1) / CONV_TH;
-    p.tiles_w = (gw + TW - 1) / TW;
-    const long long nz = MODE == MVD_DECONV3D_STRIDE2 ? (long long)p.Di * 8 : p.Do;
+    p.tiles_w = (gw + T::TW - 1) / T::TW;
+    const long long nz = T::DECONV ? (long long)p.Di * 4 : p.Do;
     const long long nblk = (long long)p.tiles_w * p.tiles_h * nz * p.B;
     if (nblk > 0x7fffffffLL) {
         set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
@@ -283,15 +362,32 @@ static int launch_conv(const ConvParams& p0, hipStream_t st) {
     return launch_status("conv3d");
 }
 
+static int launch_c8_to_1(const ConvParams& p0, hipStream_t st) {
+    ConvParams p = p0;
+    p.tiles_h = (p.ho + CONV_TH - 1) / CONV_TH;
+    p.tiles_w = (p.wo + 63) / 64;
+    const long long nblk = (long long)p.tiles_w * p.tiles_h * p.Do * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    hipLaunchKernelGGL(conv3d_c8_to_1_kernel, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    return launch_status("conv3d_c8_to_1");
+}
+
 template <int CIN, int MODE>
 static int dispatch_cout(const ConvParams& p, hipStream_t st) {
-    // MT (16-voxel tiles per wave) chosen so that the slab fits LDS and wide rows get long tiles
+    // MT (16-column tiles per wave) chosen so that the slab fits LDS and wide rows get long tiles
     constexpr int MT = MODE == MVD_CONV3D_STRIDE2 ? (CIN >= 32 ? 2 : 4) : 4;
+    if constexpr (MODE == MVD_CONV3D_STRIDE1) {
+        if (p.Cout == 8) return launch_conv<CIN, 1, (CIN >= 64 ? 1 : 2), MVD_CONV3D_S1_PAIR>(p, st);
+        if (p.Cout == 1 && CIN == 8) return launch_c8_to_1(p, st);
+    }
     const int nt = (p.Cout + 15) / 16;
     switch (nt) {
         case 1: return launch_conv<CIN, 1, MT, MODE>(p, st);
         case 2: return launch_conv<CIN, 2, MT, MODE>(p, st);
-        case 4: return launch_conv<CIN, 4, MT, MODE>(p, st);
+        case 4: return launch_conv<CIN, 4, (MODE == MVD_DECONV3D_STRIDE2 ? 2 : MT), MODE>(p, st);
     }
     set_error("conv3d: Cout=%d unsupported", p.Cout);
     return MVD_ERR_INVALID_ARG;
@@ -317,7 +413,8 @@ extern "C" {
 
 size_t mvd_conv3d_packed_weight_floats(int Cin, int Cout) {
     if (!mvd::cin_ok(Cin) || !mvd::cout_ok(Cout)) return 0;
-    return (size_t)27 * Cin * 16 * ((Cout + 15) / 16);
+    // 36 taps when a stride-1 layer with 8 output channels is packed for PAIR mode
+    return (size_t)(Cout == 8 ? 36 : 27) * Cin * 16 * ((Cout + 15) / 16);
 }
 
 int mvd_pack_conv3d_weights_f32(const float* w, int Cin, int Cout, int mode, float* packed, mvd_stream_t stream) {
@@ -325,8 +422,13 @@ int mvd_pack_conv3d_weights_f32(const float* w, int Cin, int Cout, int mode, flo
     MVD_REQUIRE(mvd::cin_ok(Cin) && mvd::cout_ok(Cout), "pack_conv3d_weights: Cin=%d/Cout=%d unsupported", Cin, Cout);
     MVD_REQUIRE(mode >= 0 && mode <= 2, "pack_conv3d_weights: mode=%d unknown", mode);
     const int NT = (Cout + 15) / 16;
-    const int tr = mode == MVD_DECONV3D_STRIDE2;
+    // 1: ConvTranspose3d weight layout; 2: PAIR-mode packing (stride-1 conv with 8 output channels)
+    const int tr = mode == MVD_DECONV3D_STRIDE2 ? 1 : (mode == MVD_CONV3D_STRIDE1 && Cout == 8) ? 2 : 0;
     hipStream_t st = (hipStream_t)stream;
+    if (mode == MVD_CONV3D_STRIDE1 && Cout == 1 && Cin == 8) {  // the vector-ALU `prob` kernel takes [tap][cin]
+        hipLaunchKernelGGL(mvd::pack_c8_to_1_kernel, dim3(1), dim3(256), 0, st, w, packed);
+        return mvd::launch_status("pack_conv3d_weights");
+    }
     const unsigned nb = (unsigned)((mvd_conv3d_packed_weight_floats(Cin, Cout) + 255) / 256);
     switch (Cin) {
         case 8: hipLaunchKernelGGL(mvd::pack_weights_kernel<8>, dim3(nb), dim3(256), 0, st, w, packed, Cout, NT, tr); break;

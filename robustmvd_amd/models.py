@@ -17,6 +17,19 @@ from .registry import build_model_with_cfg, register_model
 from .utils import exclude_index, get_torch_model_device, select_by_index, to_numpy, to_torch
 
 
+def _key_positions(keyview_idx, n):
+    """keyview_idx (int, list, numpy or tensor) -> per-sample python ints.  The adapters keep it on the host; a
+    GPU tensor (the training harness moves whole samples to the device) costs one synchronising copy."""
+    if isinstance(keyview_idx, torch.Tensor):
+        keyview_idx = keyview_idx.detach().cpu().numpy()
+    k = np.asarray(keyview_idx).reshape(-1)
+    if k.size == 1:
+        return [int(k[0])] * n
+    if k.size != n:
+        raise ValueError(f"keyview_idx has {k.size} entries for a batch of {n}")
+    return [int(v) for v in k]
+
+
 def _require_multiple(images, m, what):
     h, w = images[0].shape[-2:]
     if h % m or w % m:
@@ -42,8 +55,8 @@ class RobustMVD(nn.Module):
                     nn.init.zeros_(m.bias)
 
     def forward(self, images, poses, intrinsics, keyview_idx, **_):
-        if isinstance(keyview_idx, torch.Tensor):
-            keyview_idx = keyview_idx.tolist() if keyview_idx.dim() else int(keyview_idx)
+        key_pos = _key_positions(keyview_idx, images[0].shape[0])
+        keyview_idx = key_pos[0] if all(k == key_pos[0] for k in key_pos) else key_pos
         image_key = select_by_index(images, keyview_idx)
         images_source = exclude_index(images, keyview_idx)
         intrinsics_key = select_by_index(intrinsics, keyview_idx)
@@ -81,7 +94,8 @@ class RobustMVD(nn.Module):
         images = [im / 255.0 - 0.4 for im in images]
         scale = np.array([[wd] * 3, [ht] * 3, [1.0] * 3], dtype=np.float32)  # relative intrinsics, :118-120
         intrinsics = [k / scale for k in intrinsics]
-        images, keyview_idx, poses, intrinsics = to_torch((images, keyview_idx, poses, intrinsics), device=device)
+        images, poses, intrinsics = to_torch((images, poses, intrinsics), device=device)
+        keyview_idx = to_torch(keyview_idx)  # stays on the host: only used to order the views
         images = [im.float() for im in images]
         poses = [p.float() for p in poses]
         intrinsics = [k.float() for k in intrinsics]
@@ -102,36 +116,56 @@ class MVSNet(nn.Module):
         self.cost_regularization = CostRegNet()
         self.num_sampling_steps = num_sampling_steps
         self.sample_in_inv_depth_space = False
+        self.register_buffer("intrinsics_scale", torch.tensor([[0.25] * 3, [0.25] * 3, [1.0] * 3]), persistent=False)
 
     def depth_samples(self, depth_range, n, device):
-        lo, hi = (0.2, 100.0) if depth_range is None else (float(depth_range[0][0]), float(depth_range[1][0]))
-        d = torch.linspace(lo, hi, self.num_sampling_steps, dtype=torch.float32)  # batch element 0's range, :66-73
-        return torch.stack(n * [d]).to(device)
+        """linspace(min[0], max[0], D) of batch element 0's range (mvsnet.py:66-73), computed on the device
+        with torch.linspace's own formula (start + i*step below the midpoint, end - (D-1-i)*step above)
+        so that a range that lives on the GPU never has to come back to the host."""
+        D = self.num_sampling_steps
+        if depth_range is None:
+            return torch.linspace(0.2, 100.0, D, dtype=torch.float32, device=device).expand(n, D).contiguous()
+        lo, hi = depth_range[0], depth_range[1]
+        if not (isinstance(lo, torch.Tensor) and lo.is_cuda) and not (isinstance(hi, torch.Tensor) and hi.is_cuda):
+            # host-side range (what this package's input_adapter hands over): torch.linspace itself, bit for bit
+            lo = float(torch.as_tensor(lo, dtype=torch.float32).reshape(-1)[0])
+            hi = float(torch.as_tensor(hi, dtype=torch.float32).reshape(-1)[0])
+            d = torch.linspace(lo, hi, D, dtype=torch.float32)
+            return d.expand(n, D).contiguous().to(device, non_blocking=True)
+        lo = torch.as_tensor(lo, dtype=torch.float32, device=device).reshape(-1)[0]
+        hi = torch.as_tensor(hi, dtype=torch.float32, device=device).reshape(-1)[0]
+        i = torch.arange(D, dtype=torch.float32, device=device)
+        step = (hi - lo) / (D - 1)
+        d = torch.where(i < D // 2, lo + step * i, hi - step * (D - 1 - i))
+        return d.expand(n, D).contiguous()
 
-    @staticmethod
-    def projection_matrices(intrinsics, poses, keyview_idx):
+    def projection_matrices(self, intrinsics, poses, key_pos):
         """mvsnet.py:76-103: K[:2] *= 0.25; P[:3,:4] = K @ pose[:3,:4]; the key view's P is inverted.
+        key_pos: per-sample python ints.  No host synchronisation (inv_ex does not check `info`).
         (The reference writes into the caller's pose tensors; here they are left untouched.)"""
         out = []
         for v, (K, T) in enumerate(zip(intrinsics, poses)):
-            K = K.float() * torch.tensor([[0.25] * 3, [0.25] * 3, [1.0] * 3], device=K.device)
             P = T.float().clone()
-            P[:, :3, :4] = torch.matmul(K, P[:, :3, :4])
-            is_key = torch.as_tensor(keyview_idx, device=P.device).reshape(-1) == v
-            if bool(is_key.any()):
-                P = torch.where(is_key.view(-1, 1, 1), torch.inverse(P), P)
+            P[:, :3, :4] = torch.matmul(K.float() * self.intrinsics_scale, P[:, :3, :4])
+            if any(k == v for k in key_pos):
+                inv = torch.linalg.inv_ex(P, check_errors=False).inverse
+                if all(k == v for k in key_pos):
+                    P = inv
+                else:
+                    sel = torch.tensor([k == v for k in key_pos], device=P.device).view(-1, 1, 1)
+                    P = torch.where(sel, inv, P)
             out.append(P)
         return out
 
     def forward(self, images, poses, intrinsics, keyview_idx, depth_range=None, **_):
-        if isinstance(keyview_idx, torch.Tensor):
-            keyview_idx = keyview_idx.tolist() if keyview_idx.dim() else int(keyview_idx)
         n = images[0].shape[0]
         device = images[0].device
+        key_pos = _key_positions(keyview_idx, n)
+        kidx = key_pos[0] if all(k == key_pos[0] for k in key_pos) else key_pos
         depth_samples = self.depth_samples(depth_range, n, device)
-        proj = self.projection_matrices(intrinsics, poses, keyview_idx)
-        views = [select_by_index(images, keyview_idx)] + exclude_index(images, keyview_idx)
-        projs = [select_by_index(proj, keyview_idx)] + exclude_index(proj, keyview_idx)
+        proj = self.projection_matrices(intrinsics, poses, key_pos)
+        views = [select_by_index(images, kidx)] + exclude_index(images, kidx)
+        projs = [select_by_index(proj, kidx)] + exclude_index(proj, kidx)
 
         feats = self.feature(torch.cat(views, 0))           # (V*B, 32, h, w) on MIOpen
         feats = list(torch.split(feats, n, 0))
@@ -150,8 +184,9 @@ class MVSNet(nn.Module):
         mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(-1, 1, 1)
         std = np.array([0.229, 0.224, 0.225], np.float32).reshape(-1, 1, 1)
         images = [((im / 255.0 - mean) / std).astype(np.float32) for im in images]
-        images, keyview_idx, intrinsics, poses, depth_range, masks = to_torch(
-            (images, keyview_idx, intrinsics, poses, depth_range, masks), device=device)
+        images, intrinsics, poses, masks = to_torch((images, intrinsics, poses, masks), device=device)
+        # stay on the host: keyview_idx only orders the views, depth_range only seeds torch.linspace
+        keyview_idx, depth_range = to_torch(keyview_idx), to_torch(depth_range)
         return {"images": [im.float() for im in images], "poses": poses, "intrinsics": intrinsics,
                 "keyview_idx": keyview_idx, "depth_range": depth_range, "masks": masks}
 

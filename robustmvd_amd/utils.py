@@ -85,15 +85,15 @@ def _stack(items):
 
 def select_by_index(views, idx):
     """views: list over views of (batched) items; idx: int, or per-sample indices (N,)."""
-    if isinstance(idx, int):
-        return views[idx]
+    if isinstance(idx, (int, np.integer)):
+        return views[int(idx)]
     return _stack([views[int(i)][b] for b, i in enumerate(idx)])
 
 
 def exclude_index(views, idx):
     """All views except `idx` (int or per-sample indices); order of the remaining views is kept."""
-    if isinstance(idx, int):
-        return [v for i, v in enumerate(views) if i != idx]
+    if isinstance(idx, (int, np.integer)):
+        return [v for i, v in enumerate(views) if i != int(idx)]
     per_sample = [[v[b] for i, v in enumerate(views) if i != int(ex)] for b, ex in enumerate(idx)]
     if per_sample and all(len(r) > 0 for r in per_sample):
         return [_stack(list(col)) for col in zip(*per_sample)]
