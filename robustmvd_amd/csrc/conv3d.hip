@@ -25,6 +25,7 @@
 // fewer MFMAs for the same result (each product that is kept is bit-identical; the extra ones multiply by 0).
 // Cout = 1 (the final `prob` layer) would use 1 row of 16: it has its own vector-ALU kernel below.
 #include "mvd_common.h"
+#include <stdlib.h>
 
 namespace mvd {
 
@@ -245,6 +246,15 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
     }
 
     // ---- epilogue: y = act(acc*scale + shift) (+ skip); lane holds rows 16n + 4q .. +3 of GEMM column `vox` ----
+    float esc[NT][4], esh[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = (PAIR ? 4 * (q & 1) : n * 16 + q * 4) + k;
+            esc[n][k] = ch < p.Cout ? p.scale[ch] : 0.f;
+            esh[n][k] = ch < p.Cout ? p.shift[ch] : 0.f;
+        }
     const int orow = DECONV ? 2 * (r0 + wave) + ph : r0 + wave;
     const int oz = DECONV ? 2 * zd + pd : zd;
     if (orow >= p.ho) return;
@@ -267,7 +277,7 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
                     const int ch = cb + k;
                     float val = 0.f;
                     if (ch < p.Cout) {
-                        val = fmaf(acc[c][m][n][k], p.scale[ch], p.shift[ch]);
+                        val = fmaf(acc[c][m][n][k], esc[n][k], esh[n][k]);
                         if (p.relu) val = fmaxf(val, 0.f);
                         if (p.skip) val += p.skip[o + ch];
                     }
@@ -283,53 +293,361 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
         }
 }
 
+// Stride-1 layers (plain and PAIR) in depth-marching form: a workgroup keeps its 4 x TW tile and walks DZ
+// consecutive output planes.  Three input planes live in an LDS ring; each step retires one plane, stores
+// the plane that was prefetched into registers during the previous step's MFMAs (the global loads are
+// issued before the MFMA block and only waited for after it) and computes one output plane from the three
+// resident ones.  Every input plane is staged once per tile column instead of three times, and its L2
+// latency is hidden under ~9k cycles of matrix work.
+template <int CIN, int NT, int MT, bool PAIR, int DZ>
+__global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
+    using G = KGroup<CIN>;
+    constexpr int TW = 16 * MT, SX = PAIR ? 2 : 1;
+    constexpr int ROWS = CONV_TH + 2, COLS = PAIR ? 2 * TW + 2 : TW + 2, NWT = PAIR ? 4 : 3;
+    // CIN = 32 PAIR (conv0): no per-pixel padding but an XOR swizzle of the 16-B channel chunks by the pixel-pair
+    // index, which keeps the ring at 78 KB so that TWO workgroups fit a CU (one computes while the other stages)
+    constexpr bool SWZ = PAIR && CIN == 32;
+    constexpr int PSTR = SWZ ? CIN : CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR, C4 = CIN / 4;
+    constexpr int NEL = ROWS * COLS * C4, NPF = (NEL + 255) / 256;
+    constexpr bool SPLIT = MT * NT == 1;  // a single accumulator would serialise on the MFMA's dependent latency
+    // Packed weights live in LDS when they fit beside the ring.  vmcnt retires in order, so a weight fragment
+    // fetched with global_load inside the tap loop would make every `s_waitcnt` also wait for the (older) plane
+    // prefetch and for its own L2 round trip; ds_reads use lgkmcnt and leave the prefetch in flight.
+    constexpr int WFLOATS = (PAIR ? 36 : 27) * G::NKG * NT * 64 * G::R;
+    constexpr bool WLDS = (size_t)(3 * SLAB + 4 + WFLOATS) * sizeof(float) <= 160 * 1024;
+    extern __shared__ __attribute__((aligned(16))) float ring[];  // [3][ROWS][COLS][PSTR] + dummy float4 + weights
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int vox = lane & 15, q = lane >> 4;
+
+    int bx = blockIdx.x;
+    const int tw = bx % p.tiles_w; bx /= p.tiles_w;
+    const int th = bx % p.tiles_h; bx /= p.tiles_h;
+    const int nzc = (p.Do + DZ - 1) / DZ;
+    const int zc = bx % nzc;
+    const int b = bx / nzc;
+    const int r0 = th * CONV_TH, c0 = tw * TW;
+    const int z0 = zc * DZ, z1 = min(z0 + DZ, p.Do);
+    const int in_r0 = r0 - 1, in_c0 = PAIR ? 2 * c0 - 1 : c0 - 1;
+
+    // this thread's share of a slab: LDS offset and offset inside an input plane (-1: outside the image / unused)
+    int loff[NPF], goff[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e / (COLS * C4), rem = e - row * (COLS * C4);
+        const int col = rem / C4, c4 = rem - col * C4;
+        const int gr = in_r0 + row, gc = in_c0 + col;
+        const int pc4 = SWZ ? (c4 ^ ((col >> 1) & (C4 - 1))) : c4;
+        // float4 units; elements past the slab go to a dummy slot behind the ring, loads outside the image read
+        // element 0 and are zeroed by select: every load and store is unconditional (no branches, b128 LDS stores)
+        loff[i] = e < NEL ? ((row * COLS + col) * PSTR) / 4 + pc4 : 3 * SLAB / 4;
+        goff[i] = (e < NEL && gr >= 0 && gr < p.hi && gc >= 0 && gc < p.wi) ? (gr * p.wi + gc) * C4 + c4 : -1;
+    }
+    const size_t plane_f4 = (size_t)p.hi * p.wi * C4;
+    const float4* __restrict__ xb = reinterpret_cast<const float4*>(p.x) + (size_t)b * p.Di * plane_f4;
+    float4* __restrict__ ring4 = reinterpret_cast<float4*>(ring);
+    float4 pf[NPF];
+    bool pf_ok = false;
+    auto load_plane = [&](int plane) {
+        const bool ok = plane >= 0 && plane < p.Di;  // block-uniform
+        const float4* __restrict__ xp = xb + (size_t)(ok ? plane : 0) * plane_f4;
+        pf_ok = ok;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) pf[i] = xp[max(goff[i], 0)];  // raw: zeroing happens at store time, so that
+    };                                                              // nothing touches pf while the loads are in flight
+    auto store_plane = [&](int slot) {
+        constexpr int DUMMY = 3 * SLAB / 4;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i)
+            ring4[loff[i] == DUMMY ? DUMMY : slot * (SLAB / 4) + loff[i]] =
+                (pf_ok && goff[i] >= 0) ? pf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    const float* __restrict__ wsrc = p.wpk;
+    if constexpr (WLDS) {
+        float4* __restrict__ wl4 = ring4 + 3 * SLAB / 4 + 1;
+        const float4* __restrict__ wg4 = reinterpret_cast<const float4*>(p.wpk);
+        for (int e = tid; e < WFLOATS / 4; e += 256) wl4[e] = wg4[e];
+        wsrc = ring + 3 * SLAB + 4;
+    }
+    // per-lane affine of the 4 output channels this lane owns, fetched once (inside the plane loop these
+    // per-lane loads would sit on vmcnt in front of the plane prefetch)
+    float esc[NT][4], esh[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = (PAIR ? 4 * (q & 1) : n * 16 + q * 4) + k;
+            esc[n][k] = ch < p.Cout ? p.scale[ch] : 0.f;
+            esh[n][k] = ch < p.Cout ? p.shift[ch] : 0.f;
+        }
+    load_plane(z0 - 1);
+    store_plane((z0 + 2) % 3);
+    load_plane(z0);
+    store_plane(z0 % 3);
+    load_plane(z0 + 1);
+
+    for (int z = z0; z < z1; ++z) {
+        __syncthreads();  // step z-1 no longer reads slot (z+1)%3
+        store_plane((z + 1) % 3);
+        __syncthreads();
+        if (z + 1 < z1) load_plane(z + 2);  // lands during this step's MFMAs
+
+        f32x4 acc[MT][NT], acc2[SPLIT ? 1 : MT][SPLIT ? 1 : NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT) acc2[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // One "step" = one (kd, kh) pair = NWT * NKG fragment groups.  DEEP: the fragments of step s+1 are read from
+        // LDS into a second register set before the MFMAs of step s are issued (9 steps fully unrolled, so both
+        // sets are statically indexed); a wave then always has ~1k cycles of matrix work in front of any LDS wait.
+        constexpr int NGRP = NWT * G::NKG;
+        constexpr bool DEEP = NGRP * (NT + MT) * G::R * 2 <= 160;
+        auto read_step = [&](int step, float (&A)[NGRP][NT][G::R], float (&B)[NGRP][MT][G::R]) {
+            const int kd = step / 3, kh = step - kd * 3;
+            const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;  // plane z + kd - 1
+#pragma unroll
+            for (int iw = 0; iw < NWT; ++iw) {
+                const int tap = PAIR ? step * 4 + iw : step * 3 + iw;
+                const float* __restrict__ srow_p = slab + ((wave + kh) * COLS + iw) * PSTR + (SWZ ? 0 : G::R * q);
+#pragma unroll
+                for (int g = 0; g < G::NKG; ++g) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const float* wp = wsrc + (((tap * G::NKG + g) * NT + n) * 64 + lane) * G::R;
+                        if constexpr (G::R == 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(wp);
+                            A[iw * G::NKG + g][n][0] = t.x; A[iw * G::NKG + g][n][1] = t.y;
+                            A[iw * G::NKG + g][n][2] = t.z; A[iw * G::NKG + g][n][3] = t.w;
+                        } else {
+                            const float2 t = *reinterpret_cast<const float2*>(wp);
+                            A[iw * G::NKG + g][n][0] = t.x; A[iw * G::NKG + g][n][1] = t.y;
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float* bp = srow_p + ((m * 16 + vox) * SX) * PSTR + g * G::KG;
+                        if constexpr (SWZ) bp += (((g * 4 + q) ^ ((m * 16 + vox + (iw >> 1)) & (C4 - 1))) - g * 4) * 4;
+                        if constexpr (G::R == 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(bp);
+                            B[iw * G::NKG + g][m][0] = t.x; B[iw * G::NKG + g][m][1] = t.y;
+                            B[iw * G::NKG + g][m][2] = t.z; B[iw * G::NKG + g][m][3] = t.w;
+                        } else {
+                            const float2 t = *reinterpret_cast<const float2*>(bp);
+                            B[iw * G::NKG + g][m][0] = t.x; B[iw * G::NKG + g][m][1] = t.y;
+                        }
+                    }
+                }
+            }
+        };
+        auto mfma_step = [&](float (&A)[NGRP][NT][G::R], float (&B)[NGRP][MT][G::R]) {
+#pragma unroll
+            for (int grp = 0; grp < NGRP; ++grp)
+#pragma unroll
+                for (int j = 0; j < G::R; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            if constexpr (SPLIT) {
+                                if (j & 1)
+                                    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[grp][0][j], B[grp][0][j], acc2[0][0], 0, 0, 0);
+                                else
+                                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[grp][0][j], B[grp][0][j], acc[0][0], 0, 0, 0);
+                            } else {
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[grp][n][j], B[grp][m][j], acc[m][n], 0, 0, 0);
+                            }
+                        }
+        };
+        if constexpr (DEEP) {
+            float A0[NGRP][NT][G::R], B0[NGRP][MT][G::R], A1[NGRP][NT][G::R], B1[NGRP][MT][G::R];
+            read_step(0, A0, B0);
+#pragma unroll
+            for (int step = 0; step < 9; step += 2) {
+                if (step + 1 < 9) read_step(step + 1, A1, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(A0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (step + 1 < 9) {
+                    if (step + 2 < 9) read_step(step + 2, A0, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(A1, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int step = 0; step < 9; ++step) {
+                float A0[NGRP][NT][G::R], B0[NGRP][MT][G::R];
+                read_step(step, A0, B0);
+                mfma_step(A0, B0);
+            }
+        }
+        if constexpr (SPLIT) acc[0][0] += acc2[0][0];
+
+        // ---- epilogue of plane z (same as conv3d_kernel) ----
+        const int orow = r0 + wave;
+        if (orow < p.ho) {
+            const size_t row_base = (((size_t)b * p.Do + z) * p.ho + orow) * p.wo;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gcol = c0 + m * 16 + vox;
+                const int ocol = PAIR ? 2 * gcol + (q >> 1) : gcol;
+                if (ocol >= p.wo) continue;
+                const size_t o = (row_base + ocol) * p.Cout;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int cb = PAIR ? 4 * (q & 1) : n * 16 + q * 4;
+                    if (cb >= p.Cout) continue;
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ch = cb + k;
+                        float val = 0.f;
+                        if (ch < p.Cout) {
+                            val = fmaf(acc[m][n][k], esc[n][k], esh[n][k]);
+                            if (p.relu) val = fmaxf(val, 0.f);
+                            if (p.skip) val += p.skip[o + ch];
+                        }
+                        r[k] = val;
+                    }
+                    if (cb + 3 < p.Cout) {
+                        *reinterpret_cast<float4*>(p.y + o + cb) = make_float4(r[0], r[1], r[2], r[3]);
+                    } else {
+                        for (int k = 0; k < 4; ++k)
+                            if (cb + k < p.Cout) p.y[o + cb + k] = r[k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+constexpr int MARCH_DZ = 16;
+
+template <int CIN, int NT, int MT, bool PAIR>
+static int launch_march(const ConvParams& p0, hipStream_t st) {
+    ConvParams p = p0;
+    constexpr int TW = 16 * MT;
+    constexpr int COLS = PAIR ? 2 * TW + 2 : TW + 2;
+    constexpr int PSTR = (PAIR && CIN == 32) ? CIN : CIN + CONV_PAD;
+    constexpr size_t ring_b = (size_t)3 * (CONV_TH + 2) * COLS * PSTR * sizeof(float) + 16;  // + dummy slot
+    constexpr size_t w_b = (size_t)(PAIR ? 36 : 27) * CIN * 16 * NT * sizeof(float);
+    constexpr size_t lds = ring_b + w_b <= 160 * 1024 ? ring_b + w_b : ring_b;  // weights in LDS when they fit
+    static_assert(ring_b <= 160 * 1024, "ring exceeds LDS");
+    const int gw = PAIR ? (p.wo + 1) / 2 : p.wo;
+    p.tiles_h = (p.ho + CONV_TH - 1) / CONV_TH;
+    p.tiles_w = (gw + TW - 1) / TW;
+    const long long nblk = (long long)p.tiles_w * p.tiles_h * ((p.Do + MARCH_DZ - 1) / MARCH_DZ) * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    if (nblk < 1024) return -1;  // too few depth-marching workgroups to fill 256 CUs: caller uses the plane-at-a-time kernel
+    auto kern = conv3d_march_kernel<CIN, NT, MT, PAIR, MARCH_DZ>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return launch_status("conv3d: LDS attribute");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    return launch_status("conv3d_march");
+}
+
 // `prob`: 3x3x3, 8 -> 1 channels, stride 1 (mvsnet_components.py:109).  One GEMM row of 16 would be used on
 // the matrix cores, so this layer runs on the vector ALU: one lane per output voxel, the three input planes
 // of a 4 x 64 tile resident in LDS (48-B pixels: conflict-free ds_read_b128 across consecutive columns), the
 // 216 weights through the scalar cache.  packed weights here are [tap 27][cin 8].
 __global__ void __launch_bounds__(256) conv3d_c8_to_1_kernel(ConvParams p) {
-    constexpr int CIN = 8, TW = 64, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN + CONV_PAD;
-    __shared__ __attribute__((aligned(16))) float slab[3 * ROWS * COLS * PSTR];  // 57 KB
+    // depth-marching like conv3d_march_kernel: 3 input planes of the 4 x 64 tile in an LDS ring, the next plane
+    // prefetched into registers while the current output plane is computed
+    constexpr int CIN = 8, TW = 64, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR;
+    constexpr int NEL = ROWS * COLS * 2, NPF = (NEL + 255) / 256, DZ = 16;
+    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 216 + 4];  // 57 KB + the weights + dummy slot
+    // the 216 weights sit in LDS (broadcast reads): scalar-cache loads inside the tap loop would share lgkmcnt
+    // with the ds_reads and, returning out of order, force a full drain per tap
+    float* __restrict__ wts = ring + 3 * SLAB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 216) wts[tid] = p.wpk[tid];
     int bx = blockIdx.x;
     const int tw = bx % p.tiles_w; bx /= p.tiles_w;
     const int th = bx % p.tiles_h; bx /= p.tiles_h;
-    const int zd = bx % p.Do;
-    const int b = bx / p.Do;
+    const int nzc = (p.Do + DZ - 1) / DZ;
+    const int zc = bx % nzc;
+    const int b = bx / nzc;
     const int r0 = th * CONV_TH, c0 = tw * TW;
-    for (int r = wave; r < 3 * ROWS; r += 4) {
-        const int kd = r / ROWS, row = r - kd * ROWS;
-        const int plane = zd + kd - 1, gr = r0 - 1 + row;
-        const bool ok = plane >= 0 && plane < p.Di && gr >= 0 && gr < p.hi;
-        const float* __restrict__ xr = p.x + (((size_t)b * p.Di + (ok ? plane : 0)) * p.hi + (ok ? gr : 0)) * p.wi * CIN;
-        for (int e = lane; e < COLS * 2; e += 64) {
-            const int col = e >> 1, c4 = e & 1, gc = c0 - 1 + col;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && gc >= 0 && gc < p.wi) v = *reinterpret_cast<const float4*>(xr + (size_t)gc * CIN + c4 * 4);
-            *reinterpret_cast<float4*>(slab + (r * COLS + col) * PSTR + c4 * 4) = v;
+    const int z0 = zc * DZ, z1 = min(z0 + DZ, p.Do);
+
+    int loff[NPF], goff[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e / (COLS * 2), rem = e - row * (COLS * 2);
+        const int col = rem >> 1, c4 = rem & 1;
+        const int gr = r0 - 1 + row, gc = c0 - 1 + col;
+        constexpr int DUMMY = (3 * SLAB + 216) / 4;
+        loff[i] = e < NEL ? ((row * COLS + col) * PSTR) / 4 + c4 : DUMMY;  // float4 units (see conv3d_march_kernel)
+        goff[i] = (e < NEL && gr >= 0 && gr < p.hi && gc >= 0 && gc < p.wi) ? (gr * p.wi + gc) * 2 + c4 : -1;
+    }
+    const size_t plane_f4 = (size_t)p.hi * p.wi * 2;
+    const float4* __restrict__ xb = reinterpret_cast<const float4*>(p.x) + (size_t)b * p.Di * plane_f4;
+    float4* __restrict__ ring4 = reinterpret_cast<float4*>(ring);
+    float4 pf[NPF];
+    bool pf_ok = false;
+    auto load_plane = [&](int plane) {
+        const bool ok = plane >= 0 && plane < p.Di;
+        const float4* __restrict__ xp = xb + (size_t)(ok ? plane : 0) * plane_f4;
+        pf_ok = ok;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) pf[i] = xp[max(goff[i], 0)];  // raw: zeroing happens at store time, so that
+    };                                                              // nothing touches pf while the loads are in flight
+    auto store_plane = [&](int slot) {
+        constexpr int DUMMY = (3 * SLAB + 216) / 4;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i)
+            ring4[loff[i] == DUMMY ? DUMMY : slot * (SLAB / 4) + loff[i]] =
+                (pf_ok && goff[i] >= 0) ? pf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    load_plane(z0 - 1);
+    store_plane((z0 + 2) % 3);
+    load_plane(z0);
+    store_plane(z0 % 3);
+    load_plane(z0 + 1);
+
+    const int orow = r0 + wave, ocol = c0 + lane;
+    const bool live = orow < p.ho && ocol < p.wo;
+    const float sc = p.scale[0], sh = p.shift[0];
+    for (int z = z0; z < z1; ++z) {
+        __syncthreads();
+        store_plane((z + 1) % 3);
+        __syncthreads();
+        if (z + 1 < z1) load_plane(z + 2);
+        float acc = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* sp = slab + ((wave + kh) * COLS + lane + kw) * PSTR;
+                    const float4 a = *reinterpret_cast<const float4*>(sp), c = *reinterpret_cast<const float4*>(sp + 4);
+                    const float4 w0 = *reinterpret_cast<const float4*>(wts + ((kd * 3 + kh) * 3 + kw) * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wts + ((kd * 3 + kh) * 3 + kw) * 8 + 4);
+                    acc = fmaf(a.x, w0.x, acc); acc = fmaf(a.y, w0.y, acc); acc = fmaf(a.z, w0.z, acc); acc = fmaf(a.w, w0.w, acc);
+                    acc = fmaf(c.x, w1.x, acc); acc = fmaf(c.y, w1.y, acc); acc = fmaf(c.z, w1.z, acc); acc = fmaf(c.w, w1.w, acc);
+                }
+        }
+        if (live) {
+            const size_t o = (((size_t)b * p.Do + z) * p.ho + orow) * p.wo + ocol;
+            float val = fmaf(acc, sc, sh);
+            if (p.relu) val = fmaxf(val, 0.f);
+            if (p.skip) val += p.skip[o];
+            p.y[o] = val;
         }
     }
-    __syncthreads();
-    float acc = 0.f;
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const float* sp = slab + ((kd * ROWS + wave + kh) * COLS + lane + kw) * PSTR;
-                const float4 a = *reinterpret_cast<const float4*>(sp), c = *reinterpret_cast<const float4*>(sp + 4);
-                const float* __restrict__ wv = p.wpk + ((kd * 3 + kh) * 3 + kw) * 8;  // uniform: s_load
-                acc = fmaf(a.x, wv[0], acc); acc = fmaf(a.y, wv[1], acc); acc = fmaf(a.z, wv[2], acc); acc = fmaf(a.w, wv[3], acc);
-                acc = fmaf(c.x, wv[4], acc); acc = fmaf(c.y, wv[5], acc); acc = fmaf(c.z, wv[6], acc); acc = fmaf(c.w, wv[7], acc);
-            }
-    const int orow = r0 + wave, ocol = c0 + lane;
-    if (orow >= p.ho || ocol >= p.wo) return;
-    const size_t o = (((size_t)b * p.Do + zd) * p.ho + orow) * p.wo + ocol;
-    float val = fmaf(acc, p.scale[0], p.shift[0]);
-    if (p.relu) val = fmaxf(val, 0.f);
-    if (p.skip) val += p.skip[o];
-    p.y[o] = val;
 }
 
 __global__ void pack_c8_to_1_kernel(const float* __restrict__ w, float* __restrict__ packed) {
@@ -366,7 +684,7 @@ static int launch_c8_to_1(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     p.tiles_h = (p.ho + CONV_TH - 1) / CONV_TH;
     p.tiles_w = (p.wo + 63) / 64;
-    const long long nblk = (long long)p.tiles_w * p.tiles_h * p.Do * p.B;
+    const long long nblk = (long long)p.tiles_w * p.tiles_h * ((p.Do + 15) / 16) * p.B;
     if (nblk > 0x7fffffffLL) {
         set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
         return MVD_ERR_INVALID_ARG;
@@ -380,8 +698,26 @@ static int dispatch_cout(const ConvParams& p, hipStream_t st) {
     // MT (16-column tiles per wave) chosen so that the slab fits LDS and wide rows get long tiles
     constexpr int MT = MODE == MVD_CONV3D_STRIDE2 ? (CIN >= 32 ? 2 : 4) : 4;
     if constexpr (MODE == MVD_CONV3D_STRIDE1) {
-        if (p.Cout == 8) return launch_conv<CIN, 1, (CIN >= 64 ? 1 : 2), MVD_CONV3D_S1_PAIR>(p, st);
+        const bool old = getenv("MVD_K4_NOMARCH") != nullptr;  // experiments: the plane-at-a-time kernels
+        if (p.Cout == 8) {
+            if constexpr (CIN <= 32)
+                if (!old) {
+                    const int rc = launch_march<CIN, 1, (CIN >= 32 ? 1 : 2), true>(p, st);
+                    if (rc >= 0) return rc;
+                }
+            return launch_conv<CIN, 1, (CIN >= 64 ? 1 : 2), MVD_CONV3D_S1_PAIR>(p, st);
+        }
         if (p.Cout == 1 && CIN == 8) return launch_c8_to_1(p, st);
+        if (!old && CIN >= 16) {
+            constexpr int MM = CIN == 16 ? 4 : CIN == 32 ? 2 : 1;
+            int rc = -1;
+            switch ((p.Cout + 15) / 16) {
+                case 1: rc = launch_march<CIN, 1, MM, false>(p, st); break;
+                case 2: rc = launch_march<CIN, 2, MM, false>(p, st); break;
+                case 4: rc = launch_march<CIN, 4, MM, false>(p, st); break;
+            }
+            if (rc >= 0) return rc;
+        }
     }
     const int nt = (p.Cout + 15) / 16;
     switch (nt) {
