@@ -187,32 +187,43 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
                 kh = ih;
                 srow = (S2 ? 2 : 1) * wave + ih;
             }
-#pragma unroll
-            for (int iw = 0; iw < T::NWT; ++iw) {
-                // (kernel w index or pair tap, slab column of GEMM column 0, output w-parity class)
-                constexpr int dkw[3] = {1, 0, 2}, dsc[3] = {0, 1, 0}, dcl[3] = {0, 1, 1};
+            // weight fragments of this whole (kd, kh) step first, in one batch: vmcnt retires in order, so a load +
+            // wait per tap would pay one L2 round trip per 4-16 MFMAs (when the batch is too big for the register
+            // file it is split per w-tap)
+            constexpr int dkw[3] = {1, 0, 2}, dsc[3] = {0, 1, 0}, dcl[3] = {0, 1, 1};
+            constexpr bool ABATCH = T::NWT * G::NKG * NT * G::R <= 96;
+            float afs[ABATCH ? T::NWT : 1][G::NKG][NT][G::R];
+            auto load_a = [&](int iw, float (&dst)[G::NKG][NT][G::R]) {
                 const int kw = DECONV ? dkw[iw % 3] : iw;
-                const int scol = DECONV ? dsc[iw % 3] : iw;
-                const int cls = DECONV ? dcl[iw % 3] : 0;
                 const int tap = PAIR ? (kd * 3 + kh) * 4 + kw : (kd * 3 + kh) * 3 + kw;
-                const float* __restrict__ srow_p = slab + (srow * COLS + scol) * PSTR + G::R * q;
 #pragma unroll
-                for (int g = 0; g < G::NKG; ++g) {
-                    // A fragments (weights): R floats per lane, contiguous per (tap, g, nt)
-                    float af[NT][G::R];
+                for (int g = 0; g < G::NKG; ++g)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const float* wp = p.wpk + ((((size_t)tap * G::NKG + g) * NT + n) * 64 + lane) * G::R;
                         if constexpr (G::R == 4) {
                             const float4 t = *reinterpret_cast<const float4*>(wp);
-                            af[n][0] = t.x; af[n][1] = t.y; af[n][2] = t.z; af[n][3] = t.w;
+                            dst[g][n][0] = t.x; dst[g][n][1] = t.y; dst[g][n][2] = t.z; dst[g][n][3] = t.w;
                         } else {
                             const float2 t = *reinterpret_cast<const float2*>(wp);
-                            af[n][0] = t.x; af[n][1] = t.y;
+                            dst[g][n][0] = t.x; dst[g][n][1] = t.y;
                         }
                     }
-                    // B fragments (activations) for all column tiles first, then the MFMAs round-robin over the
-                    // accumulators (a 16x16x4 f32 MFMA has a 40-cycle dependent latency but issues every 32)
+            };
+            if constexpr (ABATCH) {
+#pragma unroll
+                for (int iw = 0; iw < T::NWT; ++iw) load_a(iw, afs[iw]);
+            }
+#pragma unroll
+            for (int iw = 0; iw < T::NWT; ++iw) {
+                // (slab column of GEMM column 0, output w-parity class)
+                const int scol = DECONV ? dsc[iw % 3] : iw;
+                const int cls = DECONV ? dcl[iw % 3] : 0;
+                if constexpr (!ABATCH) load_a(iw, afs[0]);
+                float (&af)[G::NKG][NT][G::R] = afs[ABATCH ? iw : 0];
+                const float* __restrict__ srow_p = slab + (srow * COLS + scol) * PSTR + G::R * q;
+#pragma unroll
+                for (int g = 0; g < G::NKG; ++g) {
                     float bf[MT][G::R];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
@@ -233,11 +244,11 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
                             for (int n = 0; n < NT; ++n) {
                                 if constexpr (NPW == 2) {
                                     if (cls == 0)
-                                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n][j], bf[m][j], acc[0][m][n], 0, 0, 0);
+                                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][n][j], bf[m][j], acc[0][m][n], 0, 0, 0);
                                     else
-                                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n][j], bf[m][j], acc[1][m][n], 0, 0, 0);
+                                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][n][j], bf[m][j], acc[1][m][n], 0, 0, 0);
                                 } else {
-                                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n][j], bf[m][j], acc[0][m][n], 0, 0, 0);
+                                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][n][j], bf[m][j], acc[0][m][n], 0, 0, 0);
                                 }
                             }
                 }

@@ -1,0 +1,234 @@
+"""GPU parity on shapes the golden vectors do not cover — ragged sizes (not multiples of any tile), batch > 1,
+other channel counts, every conv3d mode, V up to 6 — against the CPU oracle on identical seeded inputs, and
+size-independent properties at the full BASELINE shapes (where the oracle would take too long)."""
+import numpy as np
+import pytest
+import torch
+
+import gen_common as gc
+from oracle import c_oracle as CO
+from oracle import mvd_oracle as O
+
+pytestmark = pytest.mark.gpu
+ATOL = RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def mvs_inputs(B, C, h, w, D, V, seed, rot=0.05, trans=0.15, dmin=0.5, dmax=10.0):
+    rng = np.random.default_rng(seed)
+    feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for _ in range(V + 1)]
+    K = gc.synthetic_intrinsics(h * 4, w * 4)
+    Ks = K.copy()
+    Ks[:2] *= 0.25
+
+    def proj(Tm, key):
+        P = Tm.copy()
+        P[:3, :4] = Ks @ P[:3, :4]
+        return (np.linalg.inv(P) if key else P).astype(np.float32)
+
+    key_inv = np.stack([proj(np.eye(4, dtype=np.float32), True)] * B)
+    projs = [np.stack([proj(gc.synthetic_pose(rng, rot, trans), False) for _ in range(B)]) for _ in range(V)]
+    depth = np.stack([np.linspace(dmin, dmax * (1 + 0.1 * b), D, dtype=np.float32) for b in range(B)])
+    return feats, projs, key_inv, depth
+
+
+@pytest.mark.parametrize("B,C,h,w,D,V", [(2, 32, 37, 53, 5, 3), (1, 32, 9, 70, 3, 6), (1, 8, 20, 33, 4, 2),
+                                         (1, 64, 11, 17, 3, 1), (1, 32, 64, 96, 9, 4)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_warp_variance_vs_oracle(B, C, h, w, D, V, channels_last, dev):
+    from robustmvd_amd import ops
+    feats, projs, key_inv, depth = mvs_inputs(B, C, h, w, D, V, seed=B * 1000 + h)
+    ref = CO.warp_variance(feats[0], feats[1:], projs, key_inv, depth)
+    got = ops.warp_variance(T(feats[0], dev), [T(f, dev) for f in feats[1:]], [T(p, dev) for p in projs], T(key_inv, dev),
+                            T(depth, dev), channels_last=channels_last)
+    if channels_last:
+        got = got.permute(0, 4, 1, 2, 3)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, atol=ATOL, rtol=RTOL)
+
+
+def test_warp_variance_wide_baseline_vs_oracle(dev):
+    """large rotations / translations: most samples leave the image, some planes go behind a source camera"""
+    from robustmvd_amd import ops
+    feats, projs, key_inv, depth = mvs_inputs(1, 32, 24, 40, 8, 3, seed=77, rot=0.7, trans=0.8, dmin=0.2, dmax=3.0)
+    ref = CO.warp_variance(feats[0], feats[1:], projs, key_inv, depth)
+    got = ops.warp_variance(T(feats[0], dev), [T(f, dev) for f in feats[1:]], [T(p, dev) for p in projs], T(key_inv, dev),
+                            T(depth, dev))
+    np.testing.assert_allclose(got.cpu().numpy(), ref, atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("N,C,h,w,hs,ws,S,V,batched", [(2, 64, 13, 21, 11, 19, 7, 3, True), (1, 128, 5, 40, 5, 40, 9, 1, False),
+                                                       (1, 256, 17, 16, 17, 16, 33, 2, False)])
+def test_sweep_corr_vs_oracle(N, C, h, w, hs, ws, S, V, batched, dev):
+    from robustmvd_amd import ops
+    rng = np.random.default_rng(N * 100 + C)
+    fk = rng.standard_normal((N, C, h, w)).astype(np.float32)
+    fs = [rng.standard_normal((N, C, hs, ws)).astype(np.float32) for _ in range(V)]
+    Kk = np.stack([np.array([[0.72, 0, 0.5], [0, 1.28, 0.5], [0, 0, 1]], np.float32)] * N)
+    Ks = [Kk * np.array([[1.0 + 0.05 * v], [1.0 - 0.03 * v], [1.0]], np.float32) for v in range(V)]
+    Ts = [np.stack([gc.synthetic_pose(rng, 0.08, 0.2) for _ in range(N)]) for _ in range(V)]
+    inv = O.compute_sampling_invdepths(np.full(N if batched else 1, 0.4, np.float32),
+                                       np.linspace(100.0, 1000.0, N if batched else 1).astype(np.float32), S)
+    ref_c, ref_m = CO.sweep_corr(fk, fs, Kk, Ks, Ts, inv)
+    corrs, masks = ops.sweep_corr(T(fk, dev), [T(f, dev) for f in fs], T(Kk, dev), [T(k, dev) for k in Ks],
+                                  [T(t, dev) for t in Ts], T(inv, dev))
+    for v in range(V):
+        m = masks[v].cpu().numpy()
+        mism = m != ref_m[v]
+        assert mism.mean() <= 1e-4
+        np.testing.assert_allclose(corrs[v].cpu().numpy()[~mism], ref_c[v][~mism], atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("V", [2, 3, 5])
+def test_fuse_views_vs_oracle(V, dev):
+    from robustmvd_amd import ops
+    rng = np.random.default_rng(V)
+    N, S, h, w = 2, 19, 7, 11
+    corrs = [rng.standard_normal((N, S, h, w)).astype(np.float32) for _ in range(V)]
+    masks = [(rng.uniform(size=(N, S, h, w)) > 0.4).astype(np.float32) for _ in range(V)]
+    for m in masks:
+        m[:, 3:6, 2:4, 5:] = 0
+    scores = [rng.standard_normal((N, 1, h, w)).astype(np.float32) * 3 for _ in range(V)]
+    rf, rm = CO.fuse_views(corrs, masks, scores)
+    f, m = ops.fuse_views([T(c, dev) for c in corrs], [T(x, dev) for x in masks], [T(s, dev) for s in scores])
+    assert (m.cpu().numpy() == rm).all()
+    np.testing.assert_allclose(f.cpu().numpy(), rf, atol=1e-5, rtol=1e-5)
+
+
+CONV_CASES = [  # (Cin, Cout, mode, D, h, w, relu, skip)
+    (32, 8, 0, 5, 7, 50, True, False), (32, 8, 0, 18, 9, 70, True, False), (8, 1, 0, 5, 6, 70, False, False),
+    (8, 1, 0, 19, 5, 9, False, True), (16, 16, 0, 3, 5, 19, True, False), (32, 32, 0, 4, 6, 35, True, True),
+    (64, 64, 0, 3, 5, 17, True, False), (8, 16, 1, 6, 10, 38, True, False), (16, 32, 1, 4, 8, 66, True, False),
+    (32, 64, 1, 4, 6, 34, True, False), (64, 32, 2, 2, 3, 9, True, True), (32, 16, 2, 3, 5, 20, True, True),
+    (16, 8, 2, 3, 6, 70, True, True), (8, 8, 0, 4, 5, 33, False, False), (16, 8, 0, 4, 5, 33, True, False),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,mode,D,h,w,relu,skip", CONV_CASES)
+def test_conv3d_modes_vs_oracle(Cin, Cout, mode, D, h, w, relu, skip, dev):
+    """every conv3d mode (incl. the PAIR and depth-marching forms, which need >= 1024 workgroups to be picked:
+    the second conv0 case is sized for that) on ragged extents, against the C oracle"""
+    from robustmvd_amd import ops
+    rng = np.random.default_rng(Cin * 100 + Cout + mode)
+    x = rng.standard_normal((Cin, D, h, w)).astype(np.float32)
+    wshape = (Cin, Cout, 3, 3, 3) if mode == 2 else (Cout, Cin, 3, 3, 3)
+    wgt = (rng.standard_normal(wshape) * np.sqrt(2.0 / (27 * Cin))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    if mode == 2:
+        sk = rng.standard_normal((Cout, 2 * D, 2 * h, 2 * w)).astype(np.float32) if skip else None
+        ref = CO.deconv3d(x, wgt, scale, shift, relu=relu, skip=sk)
+    else:
+        s = 2 if mode == 1 else 1
+        sk = rng.standard_normal((Cout, D // s, h // s, w // s)).astype(np.float32) if skip else None
+        ref = CO.conv3d(x, wgt, scale, shift, stride=s, relu=relu, skip=sk)
+    packed, cin, cout = ops.pack_conv3d_weights(T(wgt, dev), mode)
+    assert (cin, cout) == (Cin, Cout)
+    xt = T(x, dev)[None].permute(0, 2, 3, 4, 1).contiguous()
+    skt = T(sk, dev)[None].permute(0, 2, 3, 4, 1).contiguous() if skip else None
+    y = ops.conv3d_bn_relu(xt, packed, Cin, Cout, T(scale, dev), T(shift, dev), mode, relu=relu, skip=skt)
+    np.testing.assert_allclose(y[0].permute(3, 0, 1, 2).cpu().numpy(), ref, atol=ATOL, rtol=RTOL)
+
+
+def test_conv0_marching_large_grid_vs_oracle(dev):
+    """enough tiles (>= 1024 workgroups) that the depth-marching PAIR kernel is the one that runs, batch 2"""
+    from robustmvd_amd import ops
+    rng = np.random.default_rng(5)
+    B, Cin, Cout, D, h, w = 2, 32, 8, 40, 64, 96
+    x = rng.standard_normal((B, Cin, D, h, w)).astype(np.float32)
+    wgt = (rng.standard_normal((Cout, Cin, 3, 3, 3)) * 0.05).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    ref = np.stack([CO.conv3d(x[b], wgt, scale, shift) for b in range(B)])
+    packed, _, _ = ops.pack_conv3d_weights(T(wgt, dev), 0)
+    y = ops.conv3d_bn_relu(T(x, dev).permute(0, 2, 3, 4, 1).contiguous(), packed, Cin, Cout, T(scale, dev), T(shift, dev), 0)
+    np.testing.assert_allclose(y.permute(0, 4, 1, 2, 3).cpu().numpy(), ref, atol=ATOL, rtol=RTOL)
+    # prob layer, same grid
+    wp = (rng.standard_normal((1, 8, 3, 3, 3)) * 0.1).astype(np.float32)
+    x8 = rng.standard_normal((B, 8, D, h, w)).astype(np.float32)
+    refp = np.stack([CO.conv3d(x8[b], wp, np.ones(1, np.float32), np.array([0.3], np.float32), relu=False) for b in range(B)])
+    pk, _, _ = ops.pack_conv3d_weights(T(wp, dev), 0)
+    yp = ops.conv3d_bn_relu(T(x8, dev).permute(0, 2, 3, 4, 1).contiguous(), pk, 8, 1, torch.ones(1, device=dev),
+                            torch.full((1,), 0.3, device=dev), 0, relu=False)
+    np.testing.assert_allclose(yp[..., 0].cpu().numpy(), refp[:, 0], atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("B,D,h,w", [(2, 2, 3, 5), (1, 1, 4, 4), (1, 96, 33, 47)])
+def test_softmax_regress_vs_oracle(B, D, h, w, dev):
+    from robustmvd_amd import ops
+    rng = np.random.default_rng(D)
+    cost = (rng.standard_normal((B, D, h, w)) * 4).astype(np.float32)
+    dv = np.stack([np.linspace(0.5, 10.0, D, dtype=np.float32)] * B) if D > 1 else np.full((B, 1), 2.5, np.float32)
+    depth, conf = ops.softmax_regress(T(cost, dev), T(dv, dev))
+    rd, rc, _ = O.softmax_regress(cost, dv)
+    np.testing.assert_allclose(depth.cpu().numpy(), rd, atol=1e-5, rtol=1e-5)
+    assert np.isclose(conf.cpu().numpy(), rc, atol=1e-5, rtol=1e-5).mean() > 0.999
+
+
+# ---------------------------------------------------------------------------------------------
+# full BASELINE shapes: properties that need no oracle
+# ---------------------------------------------------------------------------------------------
+def test_full_size_warp_variance_properties(dev):
+    """headline shape 192x288x256 planes, V=4: (1) homo_warp is linear in the features, (2) the variance does not
+    depend on the order of the source views, (3) var >= -eps, (4) both output layouts agree bit for bit, (5) a D-slab
+    of the big launch equals a small launch on that slab (checked against the oracle on 2 planes)."""
+    from robustmvd_amd import ops
+    B, C, h, w, D, V = 1, 32, 192, 288, 256, 4
+    feats, projs, key_inv, depth = mvs_inputs(B, C, h, w, D, V, seed=3)
+    ft = [T(f, dev) for f in feats]
+    pt = [T(p, dev) for p in projs]
+    ki, dt = T(key_inv, dev), T(depth, dev)
+    var = ops.warp_variance(ft[0], ft[1:], pt, ki, dt, channels_last=True)
+    assert float(var.min()) > -1e-4
+    perm = [2, 0, 3, 1]
+    var_p = ops.warp_variance(ft[0], [ft[1 + i] for i in perm], [pt[i] for i in perm], ki, dt, channels_last=True)
+    assert float((var - var_p).abs().max()) < 2e-5
+    var_ncdhw = ops.warp_variance(ft[0], ft[1:], pt, ki, dt, channels_last=False)
+    assert torch.equal(var_ncdhw.permute(0, 2, 3, 4, 1), var)
+    del var_p, var_ncdhw
+    sl = [17, 200]
+    small = CO.warp_variance(feats[0], feats[1:], projs, key_inv, depth[:, sl])
+    np.testing.assert_allclose(var[0, sl].permute(3, 0, 1, 2).cpu().numpy(), small[0], atol=ATOL, rtol=RTOL)
+    del var
+    a, b = 0.7, -1.3
+    w1 = ops.homo_warp(ft[1], pt[0], ki, dt[:, :32])
+    w2 = ops.homo_warp(ft[2], pt[0], ki, dt[:, :32])
+    w12 = ops.homo_warp(a * ft[1] + b * ft[2], pt[0], ki, dt[:, :32])
+    assert float((w12 - (a * w1 + b * w2)).abs().max()) < 2e-5
+
+
+def test_full_size_regulariser_and_regression_properties(dev):
+    """headline volume through CostRegNet + soft argmin: finite, depth inside the sampled range, confidence in
+    [0, 1], and a D-slab interior equals the small run of the same slab (receptive-field check vs the oracle)."""
+    import robustmvd_amd as R
+    from robustmvd_amd import ops
+    from test_oracle_golden import costreg_shapes
+    D, h, w = 256, 192, 288
+    net = R.CostRegNet().eval()
+    sd = gc.fill_state_dict(costreg_shapes(), 11)
+    full = net.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    net.load_state_dict(full)
+    net = net.to(dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.rand((1, D, h, w, 32), device=dev, generator=g)
+    cost = net.forward_channels_last(x)
+    assert tuple(cost.shape) == (1, D, h, w) and bool(torch.isfinite(cost).all())
+    dv = torch.linspace(0.5, 10.0, D, device=dev)[None]
+    depth, conf = ops.softmax_regress(cost, dv)
+    assert float(depth.min()) >= 0.5 - 1e-4 and float(depth.max()) <= 10.0 + 1e-4
+    assert float(conf.min()) >= 0.0 and float(conf.max()) <= 1.0 + 1e-5
+    # a 32 x 32 x 48 crop re-run on its own agrees away from the crop border (receptive field of the U-Net < 30)
+    crop = x[:, 96:160, 64:128, 96:192].contiguous()
+    cc = net.forward_channels_last(crop)
+    ref = CO.cost_reg_net(crop[0].permute(3, 0, 1, 2).cpu().numpy()[None], sd)[0, 0]
+    np.testing.assert_allclose(cc[0].cpu().numpy(), ref, atol=2e-4, rtol=1e-3)
