@@ -43,6 +43,10 @@ typedef enum {
 /* layouts of a 5-D cost volume */
 #define MVD_LAYOUT_NCDHW 0 /* (B, C, D, h, w): what the reference's homo_warp / CostRegNet use */
 #define MVD_LAYOUT_NDHWC 1 /* (B, D, h, w, C): channel-last, what the engine uses between its own kernels */
+/* OR into `out_layout` of mvd_warp_variance_f32: compute the sampling positions with the reference's own
+ * operation chain (IEEE divisions, normalise then un-normalise), rounding for rounding, instead of the default
+ * folded form ix = X * rcp(Z) * W/(W-1) - 0.5.  The default is within 1e-4 px of the chain; exact costs ~40 %. */
+#define MVD_GRID_EXACT 0x100
 
 int mvd_version(void);
 /* thread-local; valid until the next failing call on this thread */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmvd_hip.so")
 MVD_MAX_VIEWS = 16
 LAYOUT_NCDHW = 0
 LAYOUT_NDHWC = 1
+GRID_EXACT = 0x100
 CONV3D_STRIDE1 = 0
 CONV3D_STRIDE2 = 1
 DECONV3D_STRIDE2 = 2

@@ -27,6 +27,7 @@ struct WarpParams {
     int B, D, h, w, V;
     int layout;             // MVD_LAYOUT_*
     int tiles_x, tiles_y, tiles_per_xcd;  // filled by the launchers
+    int exact_grid;  // 1: sampling positions follow the reference's operation chain rounding for rounding
 };
 
 // M[v][b] = (src_proj[v][b] @ key_proj_inv[b])[:3,:4] as an fmaf chain over k (what a K=4 sgemm does):
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
     const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
     const float fx = (float)xc, fy = (float)y;
     const float xhi = (float)w, yhi = (float)h;
+    const float half_w = (float)(w - 1) / 2.0f, half_h = (float)(h - 1) / 2.0f;
     const int W2 = w + 3;
     const unsigned rowb = (unsigned)W2 * PIX;                    // bytes per padded row
     const unsigned img_bytes = (unsigned)(h + 3) * rowb;         // bytes per padded image
@@ -159,11 +161,25 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
         float wx[DPB], wy[DPB];
 #pragma unroll
         for (int i = 0; i < DPB; ++i) {
-            const float X = fmaf(ax, dep[i], tx), Y = fmaf(ay, dep[i], ty), Z = fmaf(az, dep[i], tz);
-            const float rz = __builtin_amdgcn_rcpf(Z);
+            float ix, iy;
+            if (p.exact_grid) {
+                // the reference's own chain, one rounding per step: R @ (x*d, y*d, d) + T (utils.py:246-250), perspective
+                // divide, /((W-1)/2) - 1 (:256-257), grid_sample's ((g+1)*W-1)/2
+                const float gx = fx * dep[i], gy = fy * dep[i];
+                const float X = ((M[0] * gx + M[1] * gy) + M[2] * dep[i]) + tx;
+                const float Y = ((M[4] * gx + M[5] * gy) + M[6] * dep[i]) + ty;
+                const float Z = ((M[8] * gx + M[9] * gy) + M[10] * dep[i]) + tz;
+                ix = unnormalize_coord((X / Z) / half_w - 1.0f, xhi);
+                iy = unnormalize_coord((Y / Z) / half_h - 1.0f, yhi);
+            } else {
+                const float X = fmaf(ax, dep[i], tx), Y = fmaf(ay, dep[i], ty), Z = fmaf(az, dep[i], tz);
+                const float rz = __builtin_amdgcn_rcpf(Z);
+                ix = fmaf(X * rz, sx, -0.5f);
+                iy = fmaf(Y * rz, sy, -0.5f);
+            }
             // clamp into the zero border: a sample outside the image lands on zero taps; NaN (Z == 0) clamps to -1
-            const float ix = fminf(fmaxf(fmaf(X * rz, sx, -0.5f), -1.0f), xhi);
-            const float iy = fminf(fmaxf(fmaf(Y * rz, sy, -0.5f), -1.0f), yhi);
+            ix = fminf(fmaxf(ix, -1.0f), xhi);
+            iy = fminf(fmaxf(iy, -1.0f), yhi);
             const float xf = floorf(ix), yf = floorf(iy);
             wx[i] = ix - xf;
             wy[i] = iy - yf;
@@ -583,8 +599,9 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
     p.depth = depth_values;
     p.out = out;
     p.B = B; p.D = D; p.h = h; p.w = w; p.V = V;
-    p.layout = layout;
-    if (!warp_only && C == 32 && layout == MVD_LAYOUT_NDHWC) {
+    p.layout = layout & 0xff;
+    p.exact_grid = (layout & MVD_GRID_EXACT) ? 1 : 0;
+    if (!warp_only && C == 32 && p.layout == MVD_LAYOUT_NDHWC && !p.exact_grid) {
         // MVD_K3_CFG="lds,nd" selects the LDS-staged form (experiments)
         if (const char* e = getenv("MVD_K3_CFG"))
             if (e[0] == 'l') {
@@ -613,7 +630,7 @@ int mvd_warp_variance_f32(const float* key_feat, const float* const* src_feat, c
                           mvd_stream_t stream) {
     MVD_REQUIRE(key_feat && src_feat && src_proj && key_proj_inv && depth_values && var_out,
                 "warp_variance: NULL argument");
-    MVD_REQUIRE(out_layout == MVD_LAYOUT_NCDHW || out_layout == MVD_LAYOUT_NDHWC, "warp_variance: bad layout");
+    MVD_REQUIRE((out_layout & 0xff) == MVD_LAYOUT_NCDHW || (out_layout & 0xff) == MVD_LAYOUT_NDHWC, "warp_variance: bad layout");
     return mvd::run_warp(key_feat, src_feat, src_proj, key_proj_inv, depth_values, B, C, D, h, w, V, var_out, out_layout,
                          workspace, workspace_bytes, (hipStream_t)stream, false);
 }

@@ -83,9 +83,10 @@ def fuse_views(corrs, masks, scores):
 
 
 @torch.no_grad()
-def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, channels_last=False):
+def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, channels_last=False, exact_grid=False):
     """K3. key_feat (B,C,h,w); src_feats V x (B,C,h,w); src_projs V x (B,4,4); key_proj_inv (B,4,4);
-    depth_values (B,D).  Returns the variance volume (B,C,D,h,w), or (B,D,h,w,C) if channels_last."""
+    depth_values (B,D).  Returns the variance volume (B,C,D,h,w), or (B,D,h,w,C) if channels_last.
+    exact_grid: sampling positions follow the reference's operation chain rounding for rounding (MVD_GRID_EXACT)."""
     lib = L.load()
     kf = L.as_f32(key_feat, "key_feat")
     if kf.dim() != 4:
@@ -110,7 +111,8 @@ def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, ch
     a_p, k2 = L.ptr_array(projs)
     with torch.cuda.device(dev):
         rc = lib.mvd_warp_variance_f32(L.ptr(kf), a_s, a_p, L.ptr(kpi), L.ptr(dv), B, C, D, h, w, V, L.ptr(out),
-                                       L.LAYOUT_NDHWC if channels_last else L.LAYOUT_NCDHW, L.ptr(wsp), wsb,
+                                       (L.LAYOUT_NDHWC if channels_last else L.LAYOUT_NCDHW) | (L.GRID_EXACT if exact_grid else 0),
+                                       L.ptr(wsp), wsb,
                                        L.stream_of(kf))
     L.check(rc, "mvd_warp_variance_f32")
     return out
