@@ -66,7 +66,7 @@ def adapted_sample(model, frame_idx, H, W, V, depth_range=None):
     return model.input_adapter(images=images, keyview_idx=key, poses=poses, intrinsics=intr, depth_range=dr)
 
 
-def timed_loop(model, samples, steps, warmup, world, dev, arm=None):
+def timed_loop(model, samples, steps, warmup, world, dev, arm=None, cdev=None):
     """W untimed + K timed forwards bracketed by barrier + synchronize; returns seconds (max over ranks)."""
     import torch.distributed as dist
     from robustmvd_amd.sharding import timed_region
@@ -80,7 +80,7 @@ def timed_loop(model, samples, steps, warmup, world, dev, arm=None):
 
     run(warmup, False)
     return timed_region(lambda: run(steps, True), sync=lambda: torch.cuda.synchronize(dev),
-                        dist=dist if world > 1 else None, device=dev)
+                        dist=dist if world > 1 else None, device=cdev or dev)
 
 
 def measured_copy_gbs(dev):
@@ -136,13 +136,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the engine)")
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
+    cdev = dev  # device of the tensors that go through the process group
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if ndev >= world:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:  # rehearsal with more ranks than GPUs (RCCL refuses two ranks on one device): control plane on gloo
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            cdev = torch.device("cpu")
 
+    # let MIOpen search its solvers once for the adjacent 2-D convolutions (FeatureNet / DispNet); the shapes are fixed
+    torch.backends.cudnn.benchmark = os.environ.get("MVD_BENCH_MIOPEN_FIND", "1") == "1"
     H, W, V, D = CONFIGS[args.config]
     h, w, C = H // 4, W // 4, 32
     model, sd = build_mvsnet(D, dev)
@@ -163,7 +171,7 @@ def main():
     def arm(i):
         lib.mvd_arm_kernel_timing(ev[i][0].cuda_event, ev[i][1].cuda_event)
 
-    dt = timed_loop(model, samples, args.steps, args.warmup, world, dev, arm)
+    dt = timed_loop(model, samples, args.steps, args.warmup, world, dev, arm, cdev)
     k3_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     k3_bytes = 4.0 * ((V + 1) * C * h * w + C * D * h * w)  # SURVEY.md 8(d), batch 1 per launch
     value = world * args.steps / dt
@@ -200,7 +208,7 @@ def main():
             a.record(); b.record()
         torch.cuda.synchronize(dev)
         dta = timed_loop(ma, sa, args.steps, args.warmup, world, dev,
-                         lambda i: lib.mvd_arm_kernel_timing(eva[i][0].cuda_event, eva[i][1].cuda_event))
+                         lambda i: lib.mvd_arm_kernel_timing(eva[i][0].cuda_event, eva[i][1].cuda_event), cdev)
         k1_ms = float(np.mean([a.elapsed_time(b) for a, b in eva]))
         hs, ws_ = H // 8, W // 8
         k1_bytes = 4.0 * ((V + 1) * 256 * hs * ws_ + 2 * V * 256 * hs * ws_)
