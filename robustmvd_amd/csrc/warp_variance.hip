@@ -91,7 +91,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //     with a plane-major grid every XCD streamed all V source images per plane and the gathers were
 //     served by the Infinity Cache (measured 2.8 ms at the headline shape, profiles/r01_*).
 // Placement only affects speed; results do not depend on it.
-template <int LPP, bool WARP_ONLY, int DPB, int MINW>
+template <int LPP, bool WARP_ONLY, int DPB, int MINW, bool REUSE = false>
 __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) {
     constexpr int PPB = 256 / LPP;  // pixels per block
     constexpr int C = LPP * 4;
@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
             0x00020000);
         unsigned off[DPB];
         float wx[DPB], wy[DPB];
+        bool moved[DPB];  // REUSE: the 2x2 source cell of plane i differs from plane i-1's
 #pragma unroll
         for (int i = 0; i < DPB; ++i) {
             float ix, iy;
@@ -184,14 +185,39 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
             wx[i] = ix - xf;
             wy[i] = iy - yf;
             off[i] = org + (unsigned)((int)yf * W2 + (int)xf) * PIX;  // (yf+1, xf+1) in the padded image
+            moved[i] = i == 0 || off[i] != off[i - 1];
         }
         u32x4 f[DPB][4];
+        if constexpr (REUSE) {
+            // Sweep coherence: from one plane to the next a sample moves a fraction of a pixel, so its 2x2 cell is
+            // usually the previous plane's.  Only lanes whose cell moved gather again (exec-masked loads, all issued
+            // before the first use); the others take the previous plane's registers.
 #pragma unroll
-        for (int i = 0; i < DPB; ++i) {
-            f[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
-            f[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + PIX, 0, 0);
-            f[i][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb, 0, 0);
-            f[i][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb + PIX, 0, 0);
+            for (int i = 0; i < DPB; ++i) {
+                if (moved[i]) {
+                    f[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
+                    f[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + PIX, 0, 0);
+                    f[i][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb, 0, 0);
+                    f[i][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb + PIX, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 1; i < DPB; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f[i][k].x = moved[i] ? f[i][k].x : f[i - 1][k].x;
+                    f[i][k].y = moved[i] ? f[i][k].y : f[i - 1][k].y;
+                    f[i][k].z = moved[i] ? f[i][k].z : f[i - 1][k].z;
+                    f[i][k].w = moved[i] ? f[i][k].w : f[i - 1][k].w;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < DPB; ++i) {
+                f[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
+                f[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + PIX, 0, 0);
+                f[i][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb, 0, 0);
+                f[i][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb + PIX, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < DPB; ++i) {
@@ -489,10 +515,12 @@ static int launch_warp_lds(const WarpParams& p0, hipStream_t st, int nd) {
 
 // (planes per workgroup, min waves per SIMD) — tuned on MI355X; MVD_K3_CFG="dpb,minw"
 // selects another compiled variant for experiments (C = 32 only).
-static void warp_cfg(int& dpb, int& minw) {
-    dpb = 2; minw = 6;
-    if (const char* e = getenv("MVD_K3_CFG"))
-        if (e[0] >= '0' && e[0] <= '9') sscanf(e, "%d,%d", &dpb, &minw);
+static void warp_cfg(int& dpb, int& minw, int& reuse) {
+    dpb = 4; minw = 3; reuse = 1;
+    if (const char* e = getenv("MVD_K3_CFG")) {
+        if (e[0] >= '0' && e[0] <= '9') { sscanf(e, "%d,%d", &dpb, &minw); reuse = 0; }
+        if (e[0] == 'r') { sscanf(e, "r%d,%d", &dpb, &minw); reuse = 1; }
+    }
 }
 
 static size_t padded_image_floats(int C, int h, int w) { return (size_t)(h + 3) * (w + 3) * C; }
@@ -513,9 +541,9 @@ template <bool WARP_ONLY>
 static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
     WarpParams p = p0;
     const int lpp = C / 4;
-    int dpb, minw;
-    warp_cfg(dpb, minw);
-    if (lpp != 8) { dpb = 4; minw = 3; }
+    int dpb, minw, reuse;
+    warp_cfg(dpb, minw, reuse);
+    if (lpp != 8) { dpb = 4; minw = 3; reuse = 0; }  // other channel counts: the plain variant
     const int ppb = 256 / lpp;
     p.tiles_x = (p.w + ppb - 1) / ppb;
     const long long tiles = (long long)p.tiles_x * p.h;
@@ -528,8 +556,9 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
     const dim3 grid((unsigned)nblk);
     timing_begin(st);
 #define MVD_LAUNCH(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW>), grid, dim3(256), 0, st, p)
+#define MVD_LAUNCH_R(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, true>), grid, dim3(256), 0, st, p)
     if (lpp == 8) {
-        switch (dpb * 10 + minw) {
+        switch ((reuse ? 1000 : 0) + dpb * 10 + minw) {
             case 18: MVD_LAUNCH(8, 1, 8); break;
             case 24: MVD_LAUNCH(8, 2, 4); break;
             case 28: MVD_LAUNCH(8, 2, 8); break;
@@ -538,6 +567,12 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
             case 43: MVD_LAUNCH(8, 4, 3); break;
             case 44: MVD_LAUNCH(8, 4, 4); break;
             case 82: MVD_LAUNCH(8, 8, 2); break;
+            case 1024: MVD_LAUNCH_R(8, 2, 4); break;
+            case 1026: MVD_LAUNCH_R(8, 2, 6); break;
+            case 1042: MVD_LAUNCH_R(8, 4, 2); break;
+            case 1043: MVD_LAUNCH_R(8, 4, 3); break;
+            case 1044: MVD_LAUNCH_R(8, 4, 4); break;
+            case 1082: MVD_LAUNCH_R(8, 8, 2); break;
             case 83: MVD_LAUNCH(8, 8, 3); break;
             default:
                 set_error("warp_variance: MVD_K3_CFG=%d,%d is not a compiled variant", dpb, minw);
@@ -552,6 +587,7 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
         }
     }
 #undef MVD_LAUNCH
+#undef MVD_LAUNCH_R
     timing_end(st);
     return launch_status("warp_variance");
 }
