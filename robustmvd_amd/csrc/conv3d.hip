@@ -567,6 +567,170 @@ static int launch_march(const ConvParams& p0, hipStream_t st) {
     return launch_status("conv3d_march");
 }
 
+// ConvTranspose3d (k3 s2 p1 op1) with ALL 8 output parity classes in one workgroup: out[2a+p] along each axis
+// uses kernel index 1 on input a (p = 0) or indices 0 / 2 on inputs a+1 / a (p = 1), so every one of the 27 taps
+// belongs to exactly one class (bit per axis = k != 1) and reads the slab at offset (k == 0).  One slab of
+// 2 input planes x (4+1) rows x (TW+1) cols feeds a 2 x 8 x 2*TW output block: the input is staged once instead
+// of once per class, and the two w-parities of a row are written back to back (full contiguous rows).
+template <int CIN, int NT, int MT>
+__global__ void __launch_bounds__(256) deconv3d_all_kernel(ConvParams p) {
+    using G = KGroup<CIN>;
+    constexpr int TW = 16 * MT, ROWS = CONV_TH + 1, COLS = TW + 1;
+    constexpr int PSTR = CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR, C4 = CIN / 4;
+    extern __shared__ __attribute__((aligned(16))) float slab[];  // [2 planes][ROWS][COLS][PSTR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int vox = lane & 15, q = lane >> 4;
+    int bx = blockIdx.x;
+    const int tw = bx % p.tiles_w; bx /= p.tiles_w;
+    const int th = bx % p.tiles_h; bx /= p.tiles_h;
+    const int zd = bx % p.Di;
+    const int b = bx / p.Di;
+    const int r0 = th * CONV_TH, c0 = tw * TW;
+
+    // per-lane affine of this lane's 4 output channels (see conv3d_march_kernel)
+    float esc[NT][4], esh[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = n * 16 + q * 4 + k;
+            esc[n][k] = ch < p.Cout ? p.scale[ch] : 0.f;
+            esh[n][k] = ch < p.Cout ? p.shift[ch] : 0.f;
+        }
+
+    // ---- stage input planes zd and zd+1 (zero beyond the volume) ----
+    {
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(p.x);
+        float4* __restrict__ s4 = reinterpret_cast<float4*>(slab);
+        for (int r = wave; r < 2 * ROWS; r += 4) {
+            const int pl = r / ROWS, row = r - pl * ROWS;
+            const int plane = zd + pl, gr = r0 + row;
+            const bool ok = plane < p.Di && gr < p.hi;
+            const float4* __restrict__ xr = x4 + (((size_t)b * p.Di + (ok ? plane : 0)) * p.hi + (ok ? gr : 0)) * p.wi * C4;
+            for (int e = lane; e < COLS * C4; e += 64) {
+                const int col = e / C4, c4 = e - col * C4;
+                const int gc = c0 + col;
+                const float4 t = xr[(size_t)min(gc, p.wi - 1) * C4 + c4];
+                s4[((r * COLS + col) * PSTR) / 4 + c4] = (ok && gc < p.wi) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[8][MT][NT];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[c][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            // weight fragments of the 3 w-taps of this (kd, kh) in one batch (one vmcnt wait per 3 taps)
+            float af[3][G::NKG][NT][G::R];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int g = 0; g < G::NKG; ++g)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int tap = (kd * 3 + kh) * 3 + kw;
+                        const float* wp = p.wpk + ((((size_t)tap * G::NKG + g) * NT + n) * 64 + lane) * G::R;
+                        if constexpr (G::R == 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(wp);
+                            af[kw][g][n][0] = t.x; af[kw][g][n][1] = t.y; af[kw][g][n][2] = t.z; af[kw][g][n][3] = t.w;
+                        } else {
+                            const float2 t = *reinterpret_cast<const float2*>(wp);
+                            af[kw][g][n][0] = t.x; af[kw][g][n][1] = t.y;
+                        }
+                    }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                constexpr int dummy = 0; (void)dummy;
+                const int cls = ((kd != 1) << 2) | ((kh != 1) << 1) | (kw != 1);
+                const float* __restrict__ srow_p =
+                    slab + (kd == 0 ? SLAB : 0) + ((wave + (kh == 0)) * COLS + (kw == 0)) * PSTR + G::R * q;
+#pragma unroll
+                for (int g = 0; g < G::NKG; ++g) {
+                    float bf[MT][G::R];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float* bp = srow_p + (m * 16 + vox) * PSTR + g * G::KG;
+                        if constexpr (G::R == 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(bp);
+                            bf[m][0] = t.x; bf[m][1] = t.y; bf[m][2] = t.z; bf[m][3] = t.w;
+                        } else {
+                            const float2 t = *reinterpret_cast<const float2*>(bp);
+                            bf[m][0] = t.x; bf[m][1] = t.y;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < G::R; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[cls][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kw][g][n][j], bf[m][j], acc[cls][m][n], 0, 0, 0);
+                }
+            }
+        }
+
+    // ---- epilogue: 8 classes -> output voxels (2zd+pd, 2row+ph, 2col+pw) ----
+    const int arow = r0 + wave;
+    if (arow >= p.hi) return;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int pd = c >> 2, ph = (c >> 1) & 1, pw = c & 1;
+        const size_t row_base = (((size_t)b * p.Do + 2 * zd + pd) * p.ho + 2 * arow + ph) * p.wo;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int gcol = c0 + m * 16 + vox;
+            if (gcol >= p.wi) continue;
+            const size_t o = (row_base + 2 * gcol + pw) * p.Cout;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int cb = n * 16 + q * 4;
+                if (cb >= p.Cout) continue;
+                float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.skip) sk = *reinterpret_cast<const float4*>(p.skip + o + cb);  // Cout is a multiple of 4 here
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float val = fmaf(acc[c][m][n][k], esc[n][k], esh[n][k]);
+                    if (p.relu) val = fmaxf(val, 0.f);
+                    r[k] = val;
+                }
+                *reinterpret_cast<float4*>(p.y + o + cb) = make_float4(r[0] + sk.x, r[1] + sk.y, r[2] + sk.z, r[3] + sk.w);
+            }
+        }
+    }
+}
+
+template <int CIN, int NT, int MT>
+static int launch_deconv_all(const ConvParams& p0, hipStream_t st) {
+    ConvParams p = p0;
+    constexpr size_t lds = (size_t)2 * (CONV_TH + 1) * (16 * MT + 1) * (CIN + CONV_PAD) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "slab exceeds LDS");
+    p.tiles_h = (p.hi + CONV_TH - 1) / CONV_TH;
+    p.tiles_w = (p.wi + 16 * MT - 1) / (16 * MT);
+    const long long nblk = (long long)p.tiles_w * p.tiles_h * p.Di * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    auto kern = deconv3d_all_kernel<CIN, NT, MT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return launch_status("conv3d: LDS attribute");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    return launch_status("deconv3d_all");
+}
+
 // `prob`: 3x3x3, 8 -> 1 channels, stride 1 (mvsnet_components.py:109).  One GEMM row of 16 would be used on
 // the matrix cores, so this layer runs on the vector ALU: one lane per output voxel, the three input planes
 // of a 4 x 64 tile resident in LDS (48-B pixels: conflict-free ds_read_b128 across consecutive columns), the
@@ -731,6 +895,13 @@ static int dispatch_cout(const ConvParams& p, hipStream_t st) {
         }
     }
     const int nt = (p.Cout + 15) / 16;
+    if constexpr (MODE == MVD_DECONV3D_STRIDE2) {
+        // all 8 parity classes per workgroup (Cout a multiple of 4); MVD_K4_DECONV_CLASSES=1 keeps the per-class kernel
+        if (p.Cout % 4 == 0 && nt <= 2 && !getenv("MVD_K4_DECONV_CLASSES")) {
+            if (nt == 1) return launch_deconv_all<CIN, 1, 2>(p, st);
+            return launch_deconv_all<CIN, 2, (CIN >= 64 ? 1 : 2)>(p, st);
+        }
+    }
     switch (nt) {
         case 1: return launch_conv<CIN, 1, MT, MODE>(p, st);
         case 2: return launch_conv<CIN, 2, MT, MODE>(p, st);

@@ -116,7 +116,8 @@ class MVSNet(nn.Module):
         self.cost_regularization = CostRegNet()
         self.num_sampling_steps = num_sampling_steps
         self.sample_in_inv_depth_space = False
-        self.register_buffer("intrinsics_scale", torch.tensor([[0.25] * 3, [0.25] * 3, [1.0] * 3]), persistent=False)
+        self._intrinsics_scale_host = torch.tensor([[0.25] * 3, [0.25] * 3, [1.0] * 3])  # feature maps are 1/4 resolution
+        self.register_buffer("intrinsics_scale", self._intrinsics_scale_host.clone(), persistent=False)
 
     def depth_samples(self, depth_range, n, device):
         """linspace(min[0], max[0], D) of batch element 0's range (mvsnet.py:66-73), computed on the device
@@ -139,22 +140,29 @@ class MVSNet(nn.Module):
         d = torch.where(i < D // 2, lo + step * i, hi - step * (D - 1 - i))
         return d.expand(n, D).contiguous()
 
-    def projection_matrices(self, intrinsics, poses, key_pos):
+    def projection_matrices(self, intrinsics, poses, key_pos, device):
         """mvsnet.py:76-103: K[:2] *= 0.25; P[:3,:4] = K @ pose[:3,:4]; the key view's P is inverted.
-        key_pos: per-sample python ints.  No host synchronisation (inv_ex does not check `info`).
-        (The reference writes into the caller's pose tensors; here they are left untouched.)"""
+        key_pos: per-sample python ints.  Calibration that is still on the host (what this package's
+        input_adapter hands over) is processed there — a handful of 4x4 products — and uploaded as ONE packed
+        tensor; calibration that already lives on the GPU is processed on the GPU without host synchronisation
+        (inv_ex does not check `info`).  The reference writes into the caller's pose tensors; here they are untouched."""
+        on_host = not intrinsics[0].is_cuda and not poses[0].is_cuda
+        scale = self._intrinsics_scale_host if on_host else self.intrinsics_scale
         out = []
         for v, (K, T) in enumerate(zip(intrinsics, poses)):
             P = T.float().clone()
-            P[:, :3, :4] = torch.matmul(K.float() * self.intrinsics_scale, P[:, :3, :4])
+            P[:, :3, :4] = torch.matmul(K.float() * scale, P[:, :3, :4])
             if any(k == v for k in key_pos):
-                inv = torch.linalg.inv_ex(P, check_errors=False).inverse
+                inv = torch.linalg.inv(P) if on_host else torch.linalg.inv_ex(P, check_errors=False).inverse
                 if all(k == v for k in key_pos):
                     P = inv
                 else:
                     sel = torch.tensor([k == v for k in key_pos], device=P.device).view(-1, 1, 1)
                     P = torch.where(sel, inv, P)
             out.append(P)
+        if on_host:
+            packed = torch.stack(out, 0).to(device, non_blocking=True)  # (V+1, B, 4, 4)
+            out = list(packed.unbind(0))
         return out
 
     def forward(self, images, poses, intrinsics, keyview_idx, depth_range=None, **_):
@@ -163,7 +171,7 @@ class MVSNet(nn.Module):
         key_pos = _key_positions(keyview_idx, n)
         kidx = key_pos[0] if all(k == key_pos[0] for k in key_pos) else key_pos
         depth_samples = self.depth_samples(depth_range, n, device)
-        proj = self.projection_matrices(intrinsics, poses, key_pos)
+        proj = self.projection_matrices(intrinsics, poses, key_pos, device)
         views = [select_by_index(images, kidx)] + exclude_index(images, kidx)
         projs = [select_by_index(proj, kidx)] + exclude_index(proj, kidx)
 
@@ -184,9 +192,10 @@ class MVSNet(nn.Module):
         mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(-1, 1, 1)
         std = np.array([0.229, 0.224, 0.225], np.float32).reshape(-1, 1, 1)
         images = [((im / 255.0 - mean) / std).astype(np.float32) for im in images]
-        images, intrinsics, poses, masks = to_torch((images, intrinsics, poses, masks), device=device)
-        # stay on the host: keyview_idx only orders the views, depth_range only seeds torch.linspace
-        keyview_idx, depth_range = to_torch(keyview_idx), to_torch(depth_range)
+        images, masks = to_torch((images, masks), device=device)
+        # stay on the host: keyview_idx only orders the views, depth_range only seeds torch.linspace, and the 4x4
+        # calibration products are cheaper there than as a dozen tiny launches (forward accepts either placement)
+        keyview_idx, depth_range, intrinsics, poses = to_torch((keyview_idx, depth_range, intrinsics, poses))
         return {"images": [im.float() for im in images], "poses": poses, "intrinsics": intrinsics,
                 "keyview_idx": keyview_idx, "depth_range": depth_range, "masks": masks}
 

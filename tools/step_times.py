@@ -27,7 +27,7 @@ with torch.no_grad():
         e0 = ev()
         n = 1
         depth_samples = model.depth_samples(s["depth_range"], n, dev)
-        proj = model.projection_matrices(s["intrinsics"], s["poses"], [0])
+        proj = model.projection_matrices(s["intrinsics"], s["poses"], [0], dev)
         e1 = ev()
         feats = list(torch.split(model.feature(torch.cat(s["images"], 0)), n, 0))
         e2 = ev()
