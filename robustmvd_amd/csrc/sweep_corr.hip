@@ -3,17 +3,20 @@
 // epipolar coefficients (:228-300), sampling grids with non-finite replacement (:333-349), visibility
 // mask (:489-512) and TorchCorr (:152-195, warp() :49-104) for all V source views in one launch.
 //
-// The reference materialises the (h*w)x(hs*ws) all-pairs matrix per view (764 MB at 96x144) and
-// interpolates it; here each (key pixel, plane) sample gathers its 4 bilinear taps straight from a
-// channel-last copy of the source features (1 KB per pixel at C=256) and reduces the C-long dot
-// product inside a 16-lane group, so neither the all-pairs matrix nor the sampling grids ever exist
-// in memory.  HBM traffic is the feature maps in and 2*V*S*h*w floats out; the kernel is bound by
-// L1 gather bandwidth and vector FMA, not HBM.
-//
-// Mapping: a wave = 4 groups of 16 lanes; group g works on plane s = 4*i + g of ONE key pixel, its 16
-// lanes each own C/16 channels (C/64 float4 chunks, chunk j covering channels 64*j + 4*lane..+3, so a
-// group's load of one chunk is 256 contiguous bytes).  A workgroup (4 waves) covers 16 consecutive key
-// pixels of one row for one view; results are staged in LDS and written as 64-B row segments.
+// The reference materialises the (h*w)x(hs*ws) all-pairs matrix per view (764 MB at 96x144) and interpolates it.
+// Here the same quantity is evaluated LAZILY along each key pixel's epipolar segment: consecutive inverse-depth
+// planes move the sample by 0.07-0.3 px, so most planes share the 2x2 source cell of their predecessor, and the
+// four dot products <f_key, f_src(tap)> depend only on the cell.  One wave owns one (key pixel, view):
+//   * geometry: lane l evaluates plane s0 + l (64 planes per pass, no redundancy): sample position, bilinear
+//     weights, in-bounds mask, visibility, and the index of its 2x2 cell in the zero-bordered source copy;
+//   * cells: a ballot over "my cell differs from my neighbour's" lists the distinct cells of the pass; for each one
+//     (wave-uniform loop) the 64 lanes switch role to channel slices, load the four taps (1 KB each at C = 256:
+//     one fully coalesced instruction per tap), form the four dots with a 7-shuffle multi-value reduction, and
+//     every plane lane whose cell it is blends them with its own weights.
+// Neither the all-pairs matrix nor the sampling grids ever exist in memory, and the gather + reduction work is
+// per distinct cell (~60 per pixel and view at 96x144x256 planes) instead of per plane (256).
+// HBM traffic is the feature maps in and 2*V*S*h*w floats out; the kernel is bound by L1 gather bandwidth and
+// vector ALU, not HBM.  Results are staged in LDS and written as 64-B row segments.
 #include "mvd_common.h"
 
 namespace mvd {
@@ -70,22 +73,41 @@ __device__ __forceinline__ float replace_nonfinite(float v) {
     return v;
 }
 
-template <int NJ>  // C = 64 * NJ
+// sum of 4 values over the 64 lanes with 7 shuffles: after two select+exchange steps lane l holds a partial of value
+// (l & 3), four butterfly steps finish it; value k is read back from lane k.
+__device__ __forceinline__ void wave_sum4(float& v0, float& v1, float& v2, float& v3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float a = b0 ? v1 : v0, x = b0 ? v0 : v1;
+    a += __shfl_xor(x, 1);
+    float c = b0 ? v3 : v2, y = b0 ? v2 : v3;
+    c += __shfl_xor(y, 1);
+    float e = b1 ? c : a, z = b1 ? a : c;
+    e += __shfl_xor(z, 2);
+    e += __shfl_xor(e, 4);
+    e += __shfl_xor(e, 8);
+    e += __shfl_xor(e, 16);
+    e += __shfl_xor(e, 32);
+    v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 0));
+    v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 1));
+    v2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 2));
+    v3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 3));
+}
+
+template <int NJ>  // C = 64 * NJ: lane l owns channels [l*NJ, l*NJ + NJ)
 __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
     extern __shared__ __attribute__((aligned(16))) float res[];  // [2][S][SWEEP_PX]
     constexpr int C = 64 * NJ;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int cl = lane & 15;  // channel lane within the group
-    const int grp = lane >> 4; // plane slot within the wave
     const int y = blockIdx.y;
     const int v = blockIdx.z % p.V;
     const int n = blockIdx.z / p.V;
     const int x0 = blockIdx.x * SWEEP_PX;
     const int h = p.h, w = p.w, hs = p.hs, ws = p.ws, S = p.S;
+    const int W2 = ws + 3;  // zero-bordered source: pixel (yy, xx) at padded (yy+1, xx+1)
 
     const Epi E = epipolar(p.K_key + n * 9, p.K_src.p[v] + n * 9, p.T.p[v] + n * 16, h, w, hs, ws);
-    const float* __restrict__ src = p.src.p[v] + (size_t)n * hs * ws * C + cl * 4;
+    const float* __restrict__ src = p.src.p[v] + (size_t)n * (hs + 3) * W2 * C + lane * NJ;
     const float* __restrict__ invd = p.invd + (size_t)n * p.invd_stride;
     const float inv_sqrt_c = 1.0f / sqrtf((float)C);
     const float fws = (float)ws, fhs = (float)hs;
@@ -101,13 +123,16 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
         const float k_inf = (E.j * xc + E.k * yc) + E.l;
         const float z_pole = -(E.m / k_inf);  // :330
 
-        float4 kf[NJ];
-        const float* kp = p.key + (((size_t)n * h + y) * w + x) * C + cl * 4;
+        float kf[NJ];
+        const float* kp = p.key + (((size_t)n * h + y) * w + x) * C + lane * NJ;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) kf[j] = *reinterpret_cast<const float4*>(kp + 64 * j);
+        for (int j = 0; j < NJ; ++j) kf[j] = kp[j];
 
-        for (int s = grp; s < S; s += 4) {
-            const float ds = invd[s];
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            // ---- geometry of plane s0 + lane ----
+            const int s = s0 + lane;
+            const bool live = s < S;
+            const float ds = invd[live ? s : S - 1];
             const float den = k_inf + E.m * ds;
             const float us = replace_nonfinite((u_inf + E.e * ds) / den);  // :334
             const float vs = replace_nonfinite((v_inf + E.i * ds) / den);  // :343
@@ -117,30 +142,38 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
             // warp(): grid = 2*u/w_x - 1 (:87-88), then grid_sample's unnormalisation
             const float ix = unnormalize_coord(2.0f * us / fws - 1.0f, fws);
             const float iy = unnormalize_coord(2.0f * vs / fhs - 1.0f, fhs);
-            const Taps t = bilinear_taps(ix, iy, hs, ws);
+            const Taps t = bilinear_taps(ix, iy, hs, ws);  // weights are 0 on out-of-image taps
+            // mask[mask < 0.9999] = 0; mask[mask > 0] = 1 (:101-102), times the visibility mask (:191-193)
+            const float mk = (t.inb < 0.9999f || !visible) ? 0.f : 1.f;
+            // 2x2 cell in the zero-bordered copy; a cell entirely outside the image has all-zero weights, so which
+            // (valid) cell stands in for it does not matter
+            const int cx = (int)fminf(fmaxf(floorf(ix), -1.0f), (float)(ws - 1)) + 1;
+            const int cy = (int)fminf(fmaxf(floorf(iy), -1.0f), (float)(hs - 1)) + 1;
+            const int cell = live ? cy * W2 + cx : -1;
+
+            // ---- distinct cells of this pass ----
+            const int prev = __shfl_up(cell, 1);
+            unsigned long long todo = __ballot(live && (lane == 0 || cell != prev));
             float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float* sp = src + (size_t)t.off[k] * C;
-                float dot = 0.f;
+            while (todo) {  // wave-uniform
+                const int first = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int cu = __builtin_amdgcn_readlane(cell, first);
+                const float* __restrict__ sp = src + (size_t)cu * C;
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const float4 f = *reinterpret_cast<const float4*>(sp + 64 * j);
-                    dot = fmaf(kf[j].x, f.x, dot);
-                    dot = fmaf(kf[j].y, f.y, dot);
-                    dot = fmaf(kf[j].z, f.z, dot);
-                    dot = fmaf(kf[j].w, f.w, dot);
+                    d0 = fmaf(kf[j], sp[j], d0);
+                    d1 = fmaf(kf[j], sp[C + j], d1);
+                    d2 = fmaf(kf[j], sp[(size_t)W2 * C + j], d2);
+                    d3 = fmaf(kf[j], sp[(size_t)W2 * C + C + j], d3);
                 }
-                acc = fmaf(dot, t.w[k], acc);
+                wave_sum4(d0, d1, d2, d3, lane);
+                // corr = sum_taps w_tap * <f_key, f_src(tap)>, taps in grid_sample's order nw, ne, sw, se
+                const float blended = fmaf(d3, t.w[3], fmaf(d2, t.w[2], fmaf(d1, t.w[1], d0 * t.w[0])));
+                acc = cell == cu ? blended : acc;
             }
-            // sum over the 16 channel lanes of the group
-            acc += __shfl_xor(acc, 8, 16);
-            acc += __shfl_xor(acc, 4, 16);
-            acc += __shfl_xor(acc, 2, 16);
-            acc += __shfl_xor(acc, 1, 16);
-            if (cl == 0) {
-                // mask[mask < 0.9999] = 0; mask[mask > 0] = 1 (:101-102), times the visibility mask (:191-193)
-                const float mk = (t.inb < 0.9999f || !visible) ? 0.f : 1.f;
+            if (live) {
                 res[s * SWEEP_PX + pi] = acc * inv_sqrt_c * mk;
                 res[(S + s) * SWEEP_PX + pi] = mk;
             }
@@ -161,6 +194,8 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
 }
 
 int transpose_launch(const float* src, float* dst, int N, long long rows, long long cols, hipStream_t st);
+int repack_padded_launch(const float* src, float* dst, int B, int C, int h, int w, hipStream_t st);
+size_t padded_slot_bytes_public(int B, int C, int h, int w);
 
 }  // namespace mvd
 
@@ -168,8 +203,8 @@ extern "C" {
 
 size_t mvd_sweep_corr_workspace_bytes(int N, int C, int h, int w, int hs, int ws, int V) {
     if (N <= 0 || C <= 0 || h <= 0 || w <= 0 || hs <= 0 || ws <= 0 || V <= 0) return 0;
-    return mvd::align_up((size_t)N * C * h * w * sizeof(float), 256) +
-           (size_t)V * mvd::align_up((size_t)N * C * hs * ws * sizeof(float), 256);
+    // channel-last key copy + V zero-bordered channel-last source copies ((hs+3) x (ws+3) pixels each)
+    return mvd::align_up((size_t)N * C * h * w * sizeof(float), 256) + (size_t)V * mvd::padded_slot_bytes_public(N, C, hs, ws);
 }
 
 int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
@@ -182,6 +217,7 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
     MVD_REQUIRE(N > 0 && h > 0 && w > 0 && hs > 0 && ws > 0 && S > 0, "sweep_corr: non-positive dimension");
     MVD_REQUIRE(V >= 1 && V <= MVD_MAX_VIEWS, "sweep_corr: V=%d outside 1..%d", V, MVD_MAX_VIEWS);
     MVD_REQUIRE(C % 64 == 0 && C >= 64 && C <= 512, "sweep_corr: C=%d must be a multiple of 64 in 64..512", C);
+    MVD_REQUIRE((long long)(hs + 3) * (ws + 3) * C < 0x7fffffffLL, "sweep_corr: source map %dx%dx%d too large", hs, ws, C);
     MVD_REQUIRE(h <= 65535 && (long long)N * V <= 65535, "sweep_corr: h or N*V exceeds 65535");
     const size_t lds = (size_t)2 * S * mvd::SWEEP_PX * sizeof(float);
     MVD_REQUIRE(lds <= 160 * 1024, "sweep_corr: S=%d needs %zu B of LDS (> 160 KiB)", S, lds);
@@ -197,10 +233,10 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
     if (rc) return rc;
     p.key = wsp;
     wsp += mvd::align_up((size_t)N * C * h * w * sizeof(float), 256) / sizeof(float);
-    const size_t per = mvd::align_up((size_t)N * C * hs * ws * sizeof(float), 256) / sizeof(float);
+    const size_t per = mvd::padded_slot_bytes_public(N, C, hs, ws) / sizeof(float);
     for (int v = 0; v < V; ++v) {
         MVD_REQUIRE(feat_src[v] && K_src[v] && T_src2key[v] && corr_out[v] && mask_out[v], "sweep_corr: NULL view %d", v);
-        rc = mvd::transpose_launch(feat_src[v], wsp + v * per, N, C, (long long)hs * ws, st);
+        rc = mvd::repack_padded_launch(feat_src[v], wsp + v * per, N, C, hs, ws, st);
         if (rc) return rc;
         p.src.p[v] = wsp + v * per;
         p.K_src.p[v] = K_src[v];

@@ -537,6 +537,11 @@ static int repack_padded(const float* src, float* dst, int B, int C, int h, int 
     return launch_status("repack_padded");
 }
 
+int repack_padded_launch(const float* src, float* dst, int B, int C, int h, int w, hipStream_t st) {
+    return repack_padded(src, dst, B, C, h, w, st);
+}
+size_t padded_slot_bytes_public(int B, int C, int h, int w) { return padded_slot_bytes(B, C, h, w); }
+
 template <bool WARP_ONLY>
 static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
     WarpParams p = p0;
