@@ -2,8 +2,8 @@
 // Replaces F.softmax + depth_regression + avg_pool3d/gather of MVSNet.forward
 // (rmvd/models/mvsnet.py:139-160, rmvd/models/blocks/utils.py:271-274).
 // One lane per pixel, lanes along x: every load of a depth plane row is a coalesced 256-B segment.
-// Three sweeps over D (max, sums, 4-bin window); the cost volume is D*h*w*4 B (57 MB at the headline
-// shape) and stays in the Infinity Cache between sweeps, so HBM sees it about once.
+// One sweep over D (chunked online softmax) plus a 4-plane window re-read for the confidence; the cost volume is
+// D*h*w*4 B (57 MB at the headline shape).
 #include "mvd_common.h"
 
 namespace mvd {
@@ -18,20 +18,36 @@ __global__ void __launch_bounds__(256) softmax_regress_kernel(const float* __res
     const float* c = cost + (long long)b * D * hw + pix;
     const float* dv = depth_values + (long long)b * D;
 
-    float m = -INFINITY;
-    for (int d = 0; d < D; ++d) m = fmaxf(m, c[(long long)d * hw]);
-    float se = 0.f;
-    for (int d = 0; d < D; ++d) se += expf(c[(long long)d * hw] - m);
-    // p_d = e_d / se exactly as softmax does, then the two expectations (mvsnet.py:140-141,151-154)
-    float depth = 0.f, fidx = 0.f;
-    for (int d = 0; d < D; ++d) {
-        const float pd = expf(c[(long long)d * hw] - m) / se;
-        depth = fmaf(pd, dv[d], depth);
-        fidx = fmaf(pd, (float)d, fidx);
+    // one sweep over D in chunks of 8 planes (8 independent loads in flight per lane): online softmax that carries
+    // the running max m and the sums of e, e*depth and e*index, rescaled when a chunk raises the max
+    constexpr int CH = 8;
+    float m = -INFINITY, se = 0.f, sd = 0.f, si = 0.f;
+    for (int d0 = 0; d0 < D; d0 += CH) {
+        float v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) v[k] = d0 + k < D ? c[(long long)(d0 + k) * hw] : -INFINITY;
+        float cm = v[0];
+#pragma unroll
+        for (int k = 1; k < CH; ++k) cm = fmaxf(cm, v[k]);
+        if (cm > m) {
+            const float r = expf(m - cm);  // exp(-inf) = 0 on the first chunk
+            se *= r; sd *= r; si *= r;
+            m = cm;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (d0 + k < D) {
+                const float e = expf(v[k] - m);
+                se += e;
+                sd = fmaf(e, dv[d0 + k], sd);
+                si = fmaf(e, (float)(d0 + k), si);
+            }
+        }
     }
-    depth_out[(long long)b * hw + pix] = depth;
+    // depth = sum_d p_d depth_d, expected index = sum_d p_d d (mvsnet.py:140-141,151-154) with p_d = e_d / se
+    depth_out[(long long)b * hw + pix] = sd / se;
     if (conf_out) {
-        const int idx = (int)fidx;  // .long(): truncation (mvsnet.py:154)
+        const int idx = (int)(si / se);  // .long(): truncation (mvsnet.py:154)
         float conf = 0.f;
 #pragma unroll
         for (int j = -1; j <= 2; ++j) {
