@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
         // LDS into a second register set before the MFMAs of step s are issued (9 steps fully unrolled, so both
         // sets are statically indexed); a wave then always has ~1k cycles of matrix work in front of any LDS wait.
         constexpr int NGRP = NWT * G::NKG;
-        constexpr bool DEEP = NGRP * (NT + MT) * G::R * 2 <= 160;
+        constexpr bool DEEP = G::R == 4 && NGRP * (NT + MT) * G::R * 2 <= 160;
         auto read_step = [&](int step, float (&A)[NGRP][NT][G::R], float (&B)[NGRP][MT][G::R]) {
             const int kd = step / 3, kh = step - kd * 3;
             const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;  // plane z + kd - 1
@@ -475,19 +475,63 @@ __global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
                         }
         };
         if constexpr (DEEP) {
+            // one group of the NEXT step is fetched in front of every group of MFMAs of the CURRENT step: with one wave
+            // per SIMD nothing else can fill the matrix pipe while this wave issues address arithmetic and ds_reads, so
+            // they are spread between the MFMAs (an MFMA occupies the issue port for 8 of its 32 cycles)
             float A0[NGRP][NT][G::R], B0[NGRP][MT][G::R], A1[NGRP][NT][G::R], B1[NGRP][MT][G::R];
             read_step(0, A0, B0);
+            auto read_group = [&](int step, int grp, float (&A)[NGRP][NT][G::R], float (&B)[NGRP][MT][G::R]) {
+                const int kd = step / 3, kh = step - kd * 3;
+                const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;
+                const int iw = grp / G::NKG, g = grp - iw * G::NKG;
+                const int tap = PAIR ? step * 4 + iw : step * 3 + iw;
+                const float* __restrict__ srow_p = slab + ((wave + kh) * COLS + iw) * PSTR + (SWZ ? 0 : G::R * q);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float4 t = *reinterpret_cast<const float4*>(wsrc + (((tap * G::NKG + g) * NT + n) * 64 + lane) * G::R);
+                    A[grp][n][0] = t.x; A[grp][n][1] = t.y; A[grp][n][2] = t.z; A[grp][n][3] = t.w;
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float* bp = srow_p + ((m * 16 + vox) * SX) * PSTR + g * G::KG;
+                    if constexpr (SWZ) bp += (((g * 4 + q) ^ ((m * 16 + vox + (iw >> 1)) & (C4 - 1))) - g * 4) * 4;
+                    const float4 t = *reinterpret_cast<const float4*>(bp);
+                    B[grp][m][0] = t.x; B[grp][m][1] = t.y; B[grp][m][2] = t.z; B[grp][m][3] = t.w;
+                }
+            };
+            auto mfma_group = [&](int grp, float (&A)[NGRP][NT][G::R], float (&B)[NGRP][MT][G::R]) {
+#pragma unroll
+                for (int j = 0; j < G::R; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            if constexpr (SPLIT) {
+                                if (j & 1)
+                                    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[grp][0][j], B[grp][0][j], acc2[0][0], 0, 0, 0);
+                                else
+                                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[grp][0][j], B[grp][0][j], acc[0][0], 0, 0, 0);
+                            } else {
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[grp][n][j], B[grp][m][j], acc[m][n], 0, 0, 0);
+                            }
+                        }
+            };
+            static_assert(G::R == 4, "DEEP path assumes 16-channel k-groups");
 #pragma unroll
             for (int step = 0; step < 9; step += 2) {
-                if (step + 1 < 9) read_step(step + 1, A1, B1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_step(A0, B0);
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int grp = 0; grp < NGRP; ++grp) {
+                    if (step + 1 < 9) read_group(step + 1, grp, A1, B1);
+                    mfma_group(grp, A0, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (step + 1 < 9) {
-                    if (step + 2 < 9) read_step(step + 2, A0, B0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfma_step(A1, B1);
-                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int grp = 0; grp < NGRP; ++grp) {
+                        if (step + 2 < 9) read_group(step + 2, grp, A0, B0);
+                        mfma_group(grp, A1, B1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         } else {
