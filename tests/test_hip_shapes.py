@@ -257,3 +257,56 @@ def test_warp_variance_experimental_variants_match_default(cfg, dev, monkeypatch
     monkeypatch.setenv("MVD_K3_CFG", cfg)
     got = ops.warp_variance(*args, channels_last=True)
     assert torch.equal(got, ref)
+
+
+def test_largest_baseline_shape_runs(dev):
+    """BASELINE configs[4] (704x1280, 6 source views, 512 planes: a 3.7 GB variance volume, > 2^31 bytes per tensor):
+    the whole Path-B hot path runs, stays finite, and a D-slab of K3 matches the oracle (64-bit offsets everywhere)."""
+    import robustmvd_amd as R
+    from robustmvd_amd import ops
+    B, C, h, w, D, V = 1, 32, 176, 320, 512, 6
+    feats, projs, key_inv, depth = mvs_inputs(B, C, h, w, D, V, seed=21)
+    ft = [T(f, dev) for f in feats]
+    pt = [T(p, dev) for p in projs]
+    var = ops.warp_variance(ft[0], ft[1:], pt, T(key_inv, dev), T(depth, dev), channels_last=True)
+    assert var.numel() * 4 > 2 ** 31
+    sl = [3, 300, 511]
+    small = CO.warp_variance(feats[0], feats[1:], projs, key_inv, depth[:, sl])
+    got = var[0, sl].permute(3, 0, 1, 2).cpu().numpy()
+    assert (~np.isclose(got, small[0], atol=ATOL, rtol=RTOL)).mean() < 2e-4
+    np.testing.assert_allclose(got, small[0], atol=2e-3, rtol=2e-3)
+    net = R.CostRegNet().eval().to(dev)
+    cost = net.forward_channels_last(var)
+    del var
+    assert tuple(cost.shape) == (1, D, h, w) and bool(torch.isfinite(cost).all())
+    depth_map, conf = ops.softmax_regress(cost, T(depth, dev))
+    assert bool(torch.isfinite(depth_map).all()) and float(conf.max()) <= 1.0 + 1e-5
+
+
+def test_mvsnet_batch2_keyview1_vs_oracle_pipeline(dev):
+    """model protocol with a batch of 2 and the key view in the middle of the list, against the end-to-end oracle"""
+    import robustmvd_amd as R
+    from oracle import pipeline as PL
+    H, W, D, V = 64, 96, 16, 2
+    model = R.MVSNet(num_sampling_steps=D).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.fill_state_dict(shapes, 31)
+    full = model.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    model = R.add_run_function(model.to(dev))
+    s0, s1 = gc.synthetic_sample(40, H, W, V), gc.synthetic_sample(41, H, W, V)
+    order = [1, 0, 2]  # key view second
+    images = [np.stack([s0["images"][i], s1["images"][i]]) for i in order]
+    poses = [np.stack([s0["poses"][i], s1["poses"][i]]) for i in order]
+    intr = [np.stack([s0["intrinsics"][i], s1["intrinsics"][i]]) for i in order]
+    key = np.array([1, 1])
+    dr = (np.array([0.5, 0.5], np.float32), np.array([10.0, 10.0], np.float32))
+    pred, _ = model.run(images=images, poses=poses, intrinsics=intr, keyview_idx=key, depth_range=dr)
+    assert pred["depth"].shape == (2, 1, H // 4, W // 4)
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 3, 1, 1)
+    ref = PL.mvsnet_forward([((im / 255.0 - mean) / std).astype(np.float32) for im in images], poses, intr, 1, (0.5, 10.0), sd, D)
+    np.testing.assert_allclose(pred["depth"], ref["depth"], rtol=1e-3)
+    np.testing.assert_allclose(pred["depth_uncertainty"], ref["depth_uncertainty"], atol=2e-3)

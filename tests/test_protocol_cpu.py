@@ -1,0 +1,81 @@
+"""Model-protocol behaviour that needs no GPU: registry, checkpoint loading in the reference's format, adapters."""
+import numpy as np
+import pytest
+import torch
+
+import gen_common as gc
+
+
+def test_registry_and_errors():
+    import robustmvd_amd as R
+    assert R.list_models() == ["mvsnet_train", "robust_mvd", "robust_mvd_5M"]
+    assert R.has_model("robust_mvd") and not R.has_model("nope")
+    with pytest.raises(AssertionError, match="does not exist"):
+        R.create_model("nope")
+    with pytest.raises(RuntimeError, match="URL-only"):
+        R.create_model("robust_mvd", num_gpus=0)          # pretrained=True needs the network
+    with pytest.raises(ValueError, match="one process per GPU"):
+        R.create_model("robust_mvd", pretrained=False, num_gpus=2)
+
+
+def test_reference_format_checkpoint_loads(tmp_path):
+    """{'model_state_dict': {...}} with DataParallel's 'module.' prefix, strict=True (helpers.py:146-153)"""
+    import robustmvd_amd as R
+    src = R.RobustMVD()
+    shapes = {k: tuple(v.shape) for k, v in src.state_dict().items()}
+    sd = {("module." + k): torch.from_numpy(v) for k, v in gc.robustmvd_weights(shapes, 5).items()}
+    path = tmp_path / "ckpt.pt"
+    torch.save({"model_state_dict": sd}, path)
+    model = R.create_model("robust_mvd", weights=str(path), num_gpus=0)
+    assert model.name == "robust_mvd" and callable(model.run) and not model.training
+    got = model.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(got[k[len("module."):]], v)
+    assert sum(p.numel() for p in model.parameters()) == 42192877
+    bad = dict(sd)
+    bad.pop(next(iter(bad)))
+    torch.save({"model_state_dict": bad}, path)
+    with pytest.raises(RuntimeError):
+        R.create_model("robust_mvd", weights=str(path), num_gpus=0)
+
+
+def test_adapters_on_cpu():
+    import robustmvd_amd as R
+    m = R.RobustMVD().eval()
+    s = gc.synthetic_sample(0, 64, 128, 2)
+    from robustmvd_amd.registry import add_batch_dim
+    images, key, poses, intr, _ = add_batch_dim(s["images"], 0, s["poses"], s["intrinsics"], None)
+    out = m.input_adapter(images=images, keyview_idx=key, poses=poses, intrinsics=intr)
+    assert out["images"][0].shape == (1, 3, 64, 128) and out["images"][0].dtype == torch.float32
+    np.testing.assert_allclose(out["images"][0].numpy(), images[0] / 255.0 - 0.4, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out["intrinsics"][0][0].numpy(), intr[0][0] / np.array([[128] * 3, [64] * 3, [1] * 3], np.float32))
+    with pytest.raises(NotImplementedError, match="multiple of 64"):
+        m.input_adapter(images=[im[..., :100] for im in images], keyview_idx=key, poses=poses, intrinsics=intr)
+    mv = R.MVSNet(num_sampling_steps=8).eval()
+    o2 = mv.input_adapter(images=images, keyview_idx=key, poses=poses, intrinsics=intr, depth_range=(np.array([0.5]), np.array([9.0])))
+    mean, std = np.array([0.485, 0.456, 0.406]).reshape(1, 3, 1, 1), np.array([0.229, 0.224, 0.225]).reshape(1, 3, 1, 1)
+    np.testing.assert_allclose(o2["images"][1].numpy(), (images[1] / 255.0 - mean) / std, rtol=1e-5, atol=1e-5)
+    d = mv.depth_samples(o2["depth_range"], 1, torch.device("cpu"))
+    assert torch.equal(d[0], torch.linspace(0.5, 9.0, 8))
+    P = mv.projection_matrices(o2["intrinsics"], o2["poses"], [0], torch.device("cpu"))
+    K = intr[1][0] * np.array([[0.25] * 3, [0.25] * 3, [1.0] * 3], np.float32)
+    ref = poses[1][0].copy(); ref[:3, :4] = K @ ref[:3, :4]
+    np.testing.assert_allclose(P[1][0].numpy(), ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(P[0][0].numpy() @ np.block([[intr[0][0] * np.array([[0.25] * 3, [0.25] * 3, [1.0] * 3]) @ poses[0][0][:3, :4]], [poses[0][0][3:]]]),
+                               np.eye(4), atol=1e-4)
+
+
+def test_collate_and_index_helpers():
+    from robustmvd_amd.utils import numpy_collate, select_by_index, exclude_index, to_numpy, to_torch
+    a = [np.zeros((2, 3)), np.ones((2, 3)), 2 * np.ones((2, 3))]
+    assert select_by_index(a, 1) is a[1]
+    assert [x.sum() for x in exclude_index(a, 1)] == [0.0, 12.0]
+    b = [np.stack([np.full(3, v + 10 * n) for n in range(2)]) for v in range(3)]     # views x (batch, 3)
+    sel = select_by_index(b, np.array([2, 0]))
+    assert sel[0][0] == 2 and sel[1][0] == 10
+    exc = exclude_index(b, np.array([2, 0]))
+    assert [e[0][0] for e in exc] == [0, 1] and [e[1][0] for e in exc] == [11, 12]
+    col = numpy_collate([({"x": np.ones(2)}, 3, None), ({"x": np.zeros(2)}, 4, None)])
+    assert col[0]["x"].shape == (2, 2) and list(col[1]) == [3, 4] and col[2] is None
+    rt = to_numpy(to_torch({"a": [np.arange(3)], "b": (np.float32(1.5),)}))
+    assert rt["a"][0].tolist() == [0, 1, 2]
