@@ -145,36 +145,52 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[c][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // this thread's share of a slab (float4 units; see conv3d_march_kernel): the next input plane is fetched into
+    // registers before the current plane's MFMAs are issued and written to LDS after them
+    constexpr int C4 = CIN / 4, NEL = ROWS * COLS * C4, NPF = (NEL + 255) / 256, DUMMY = ROWS * COLS * PSTR / 4;
+    int loff[NPF], goff[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e / (COLS * C4), rem = e - row * (COLS * C4);
+        const int col = rem / C4, c4 = rem - col * C4;
+        const int gr = in_r0 + row, gc = in_c0 + col;
+        loff[i] = e < NEL ? ((row * COLS + col) * PSTR) / 4 + c4 : DUMMY;
+        goff[i] = (e < NEL && gr >= 0 && gr < p.hi && gc >= 0 && gc < p.wi) ? (gr * p.wi + gc) * C4 + c4 : -1;
+    }
+    const size_t plane_f4 = (size_t)p.hi * p.wi * C4;
+    const float4* __restrict__ xb4 = reinterpret_cast<const float4*>(p.x) + (size_t)b * p.Di * plane_f4;
+    float4* __restrict__ slab4 = reinterpret_cast<float4*>(slab);
+    float4 pf[NPF];
+    bool pf_ok = false;
+    auto plane_of = [&](int ip) {
+        if constexpr (DECONV) return pd ? (ip == 0 ? zd + 1 : zd) : zd;
+        else return SZ * zd + ip - 1;
+    };
+    auto load_plane = [&](int plane) {
+        pf_ok = plane >= 0 && plane < p.Di;  // block-uniform
+        const float4* __restrict__ xp = xb4 + (size_t)(pf_ok ? plane : 0) * plane_f4;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) pf[i] = xp[max(goff[i], 0)];
+    };
+    load_plane(plane_of(0));
+
     for (int ip = 0; ip < nplanes; ++ip) {
-        int kd, plane;
-        if constexpr (DECONV) {
-            kd = pd ? (ip == 0 ? 0 : 2) : 1;
-            plane = pd ? (ip == 0 ? zd + 1 : zd) : zd;
-        } else {
-            kd = ip;
-            plane = SZ * zd + ip - 1;
-        }
-        if (plane < 0 || plane >= p.Di) continue;  // block-uniform; contributes zeros
+        int kd;
+        if constexpr (DECONV) kd = pd ? (ip == 0 ? 0 : 2) : 1;
+        else kd = ip;
+        const int plane = plane_of(ip);
+        const bool plane_ok = plane >= 0 && plane < p.Di;  // block-uniform
 
         __syncthreads();  // previous plane's reads are done
-        // ---- stage the input rows of this plane (zero-filled halo): one wave per row, 1 KB per pass ----
-        {
-            constexpr int C4 = CIN / 4;
-            const float* __restrict__ xp = p.x + ((size_t)b * p.Di + plane) * p.hi * p.wi * CIN;
-            for (int row = wave; row < ROWS; row += 4) {
-                const int gr = in_r0 + row;
-                const bool row_ok = gr >= 0 && gr < p.hi;
-                const float* __restrict__ xr = xp + (size_t)(row_ok ? gr : 0) * p.wi * CIN;
-                for (int e = lane; e < COLS * C4; e += 64) {
-                    const int col = e / C4, c4 = e % C4;
-                    const int gc = in_c0 + col;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row_ok && gc >= 0 && gc < p.wi) v = *reinterpret_cast<const float4*>(xr + (size_t)gc * CIN + c4 * 4);
-                    *reinterpret_cast<float4*>(slab + (row * COLS + col) * PSTR + c4 * 4) = v;
-                }
-            }
+        if (plane_ok) {
+#pragma unroll
+            for (int i = 0; i < NPF; ++i)
+                slab4[loff[i]] = (pf_ok && goff[i] >= 0) ? pf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        if (ip + 1 < nplanes) load_plane(plane_of(ip + 1));  // lands during this plane's MFMAs
+        if (!plane_ok) continue;                              // an out-of-range plane contributes zeros
 
         // ---- taps of this plane ----------------------------------------------------------------
         const int nkh = DECONV ? (ph ? 2 : 1) : 3;
@@ -582,9 +598,13 @@ __global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
     }
 }
 
-constexpr int MARCH_DZ = 16;
 
-template <int CIN, int NT, int MT, bool PAIR>
+static long long march_min_blocks() {
+    static const long long v = getenv("MVD_K4_MARCH_MIN") ? atoll(getenv("MVD_K4_MARCH_MIN")) : 1024;
+    return v;
+}
+
+template <int CIN, int NT, int MT, bool PAIR, int MARCH_DZ = 16>
 static int launch_march(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     constexpr int TW = 16 * MT;
@@ -602,7 +622,11 @@ static int launch_march(const ConvParams& p0, hipStream_t st) {
         set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
         return MVD_ERR_INVALID_ARG;
     }
-    if (nblk < 1024) return -1;  // too few depth-marching workgroups to fill 256 CUs: caller uses the plane-at-a-time kernel
+    // too few depth-marching workgroups to fill 256 CUs: shorter plane chunks, then the plane-at-a-time kernel
+    if (nblk < march_min_blocks()) {
+        if constexpr (MARCH_DZ > 8) return launch_march<CIN, NT, MT, PAIR, 8>(p0, st);
+        return -1;
+    }
     auto kern = conv3d_march_kernel<CIN, NT, MT, PAIR, MARCH_DZ>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -843,7 +867,7 @@ __global__ void __launch_bounds__(256) conv3d_c8_to_1_kernel(ConvParams p) {
         store_plane((z + 1) % 3);
         __syncthreads();
         if (z + 1 < z1) load_plane(z + 2);
-        float acc = 0.f;
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;  // four independent FMA chains
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
             const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;
@@ -855,10 +879,11 @@ __global__ void __launch_bounds__(256) conv3d_c8_to_1_kernel(ConvParams p) {
                     const float4 a = *reinterpret_cast<const float4*>(sp), c = *reinterpret_cast<const float4*>(sp + 4);
                     const float4 w0 = *reinterpret_cast<const float4*>(wts + ((kd * 3 + kh) * 3 + kw) * 8);
                     const float4 w1 = *reinterpret_cast<const float4*>(wts + ((kd * 3 + kh) * 3 + kw) * 8 + 4);
-                    acc = fmaf(a.x, w0.x, acc); acc = fmaf(a.y, w0.y, acc); acc = fmaf(a.z, w0.z, acc); acc = fmaf(a.w, w0.w, acc);
-                    acc = fmaf(c.x, w1.x, acc); acc = fmaf(c.y, w1.y, acc); acc = fmaf(c.z, w1.z, acc); acc = fmaf(c.w, w1.w, acc);
+                    acc0 = fmaf(a.x, w0.x, acc0); acc1 = fmaf(a.y, w0.y, acc1); acc2 = fmaf(a.z, w0.z, acc2); acc3 = fmaf(a.w, w0.w, acc3);
+                    acc0 = fmaf(c.x, w1.x, acc0); acc1 = fmaf(c.y, w1.y, acc1); acc2 = fmaf(c.z, w1.z, acc2); acc3 = fmaf(c.w, w1.w, acc3);
                 }
         }
+        const float acc = (acc0 + acc1) + (acc2 + acc3);
         if (live) {
             const size_t o = (((size_t)b * p.Do + z) * p.ho + orow) * p.wo + ocol;
             float val = fmaf(acc, sc, sh);
@@ -878,7 +903,7 @@ template <int CIN, int NT, int MT, int MODE>
 static int launch_conv(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     using T = TileGeom<MODE, MT>;
-    constexpr size_t lds = (size_t)T::ROWS * T::COLS * (CIN + CONV_PAD) * sizeof(float);
+    constexpr size_t lds = (size_t)T::ROWS * T::COLS * (CIN + CONV_PAD) * sizeof(float) + 16;  // + dummy float4
     static_assert(lds <= 160 * 1024, "slab exceeds LDS");
     // tiles over the GEMM-column grid: output voxels (conv), voxel pairs (PAIR) or input voxels (deconv)
     const int gh = T::DECONV ? p.hi : p.ho;

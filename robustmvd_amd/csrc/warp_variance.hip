@@ -489,6 +489,228 @@ __global__ void __launch_bounds__(256, 2) warp_variance_lds_kernel(WarpParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-autonomous LDS form: like warp_variance_lds_kernel, but every WAVE owns its own 4x2 key tile and its own
+// pair of LDS buffers, so there is no workgroup barrier anywhere: a wave prefetches the footprint of view v+1 with
+// LDS-DMA into its second buffer, waits only for the OLDER copy with a counted `s_waitcnt vmcnt(N)` (the LDS-DMA
+// of the next view stays in flight) and computes view v from its first buffer.  Eight such waves per CU overlap
+// each other's latencies.  Lanes: 8 pixels (4 wide x 2 high) x 8 channel quads; ND planes per task.
+template <int ND>
+__global__ void __launch_bounds__(256, 2) warp_variance_wave_kernel(WarpParams p) {
+    constexpr int C = 32, Q = 8, TXW = 4, TYW = 2;
+    constexpr unsigned PIX = 128;
+    constexpr int RH = 4, ROWQ = 128;              // staged box: up to 4 rows x 16 pixels, row pitch 128 float4
+    constexpr int BUF = RH * ROWQ;                 // float4s per buffer (8 KiB)
+    constexpr int NDMA = RH * (ROWQ / 64);         // LDS-DMA instructions per view (always all of them: fixed count)
+    extern __shared__ __attribute__((aligned(16))) float4 wlds[];  // [4 waves][2][BUF] = 64 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 7, pp = lane >> 3;
+    const int lx = pp & 3, ly = pp >> 2;
+    const int h = p.h, w = p.w, D = p.D;
+    float4* __restrict__ mybuf = wlds + wave * 2 * BUF;
+
+    // ---- task decode: xcd | d-chunk fastest | tile group (4 x-adjacent wave tiles per workgroup) | batch ----
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int dchunks = (D + ND - 1) / ND;
+    const int dc = j % dchunks; j /= dchunks;
+    const int grp_in = j % p.tiles_per_xcd;
+    const int b = j / p.tiles_per_xcd;
+    const int grp = xcd * p.tiles_per_xcd + grp_in;   // group of 4 wave tiles = 16 x 2 pixels
+    if (grp >= p.tiles_x * p.tiles_y) return;          // block-uniform
+    const int gy = grp / p.tiles_x;
+    const int x0 = (grp - gy * p.tiles_x) * (4 * TXW) + wave * TXW, y0 = gy * TYW;
+    if (x0 >= w) return;                               // wave-uniform (ragged right edge)
+    const int d0 = dc * ND;
+    const int dl = min(d0 + ND, D) - 1;
+
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float xhi = (float)w, yhi = (float)h;
+    const int W2 = w + 3;
+    const unsigned rowb = (unsigned)W2 * PIX;
+    const unsigned img_bytes = (unsigned)(h + 3) * rowb;
+    const int xs = min(x0 + lx, w - 1), ysr = min(y0 + ly, h - 1);
+    const float fxs = (float)xs, fys = (float)ysr;
+    const float* __restrict__ dvals = p.depth + (size_t)b * D;
+    float dep[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dep[i] = dvals[min(d0 + i, D - 1)];
+    const float dfirst = dvals[d0], dlast = dvals[dl];
+    const float cxs[2] = {(float)x0, (float)min(x0 + TXW - 1, w - 1)};
+    const float cys[2] = {(float)y0, (float)min(y0 + TYW - 1, h - 1)};
+
+    float4 s1[ND], s2[ND];
+    {
+        const float4 k = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.key) + (size_t)b * img_bytes +
+                                                          (unsigned)(ysr + 1) * rowb + (unsigned)(xs + 1) * PIX + q * 16);
+        const float4 k2 = make_float4(k.x * k.x, k.y * k.y, k.z * k.z, k.w * k.w);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { s1[i] = k; s2[i] = k2; }
+    }
+
+    struct Box { int x0, y0, rw, rh; bool staged; };
+    auto footprint = [&](int v) {
+        const float* __restrict__ M = p.M + ((size_t)v * p.B + b) * 12;
+        float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f, zmin = 3e38f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float cx = cxs[a & 1], cy = cys[a >> 1];
+            const float ax = fmaf(M[0], cx, fmaf(M[1], cy, M[2])), ay = fmaf(M[4], cx, fmaf(M[5], cy, M[6]));
+            const float az = fmaf(M[8], cx, fmaf(M[9], cy, M[10]));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float cd = e ? dlast : dfirst;
+                const float X = fmaf(ax, cd, M[3]), Y = fmaf(ay, cd, M[7]), Z = fmaf(az, cd, M[11]);
+                const float rz = __builtin_amdgcn_rcpf(Z);
+                const float ix = fminf(fmaxf(fmaf(X * rz, sx, -0.5f), -1.0f), xhi);
+                const float iy = fminf(fmaxf(fmaf(Y * rz, sy, -0.5f), -1.0f), yhi);
+                bx0 = fminf(bx0, ix); bx1 = fmaxf(bx1, ix);
+                by0 = fminf(by0, iy); by1 = fmaxf(by1, iy);
+                zmin = fminf(zmin, Z);
+            }
+        }
+        Box bx;
+        bx.x0 = (int)floorf(bx0) + 1;  // padded coordinates
+        bx.y0 = (int)floorf(by0) + 1;
+        bx.rw = (int)floorf(bx1) + 3 - bx.x0;
+        bx.rh = (int)floorf(by1) + 3 - bx.y0;
+        bx.staged = zmin > 1e-6f && bx.rh <= RH && bx.rw * Q <= ROWQ;
+        // wave-uniform by construction (computed from wave-uniform inputs); make it so for the compiler too
+        bx.x0 = __builtin_amdgcn_readfirstlane(bx.x0);
+        bx.y0 = __builtin_amdgcn_readfirstlane(bx.y0);
+        bx.rw = __builtin_amdgcn_readfirstlane(bx.rw);
+        bx.rh = __builtin_amdgcn_readfirstlane(bx.rh);
+        bx.staged = __builtin_amdgcn_readfirstlane((int)bx.staged) != 0;
+        return bx;
+    };
+    // exactly NDMA LDS-DMA instructions per call (rows / columns beyond the box re-read a valid element)
+    auto dma = [&](int v, const Box& bx, float4* __restrict__ dst) {
+        const float4* __restrict__ g = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.src.p[v]) +
+                                                                         (size_t)b * img_bytes) + ((size_t)bx.y0 * W2 + bx.x0) * Q;
+        const int rowq = bx.rw * Q;
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+            const int row = min(r, bx.rh - 1);
+#pragma unroll
+            for (int c = 0; c < ROWQ / 64; ++c)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(g + (size_t)row * W2 * Q + min(lane + 64 * c, rowq - 1)),
+                    (__attribute__((address_space(3))) void*)(dst + r * ROWQ + c * 64), 16, 0, 0);
+        }
+    };
+
+    Box cur = footprint(0);
+    if (cur.staged) dma(0, cur, mybuf);
+
+    for (int v = 0; v < p.V; ++v) {
+        Box nxt = cur;
+        bool next_dma = false;
+        if (v + 1 < p.V) {
+            nxt = footprint(v + 1);
+            next_dma = nxt.staged;
+            if (next_dma) dma(v + 1, nxt, mybuf + ((v + 1) & 1) * BUF);  // streams in while view v is computed
+        }
+        // the copy of view v must have landed; the NDMA newer instructions (view v+1) may stay in flight
+        if (next_dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        const float* __restrict__ M = p.M + ((size_t)v * p.B + b) * 12;
+        const float4* __restrict__ reg = mybuf + (v & 1) * BUF;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.src.p[v]) + (size_t)b * img_bytes), 0, (int)img_bytes,
+            0x00020000);
+        const float ax = fmaf(M[0], fxs, fmaf(M[1], fys, M[2]));
+        const float ay = fmaf(M[4], fxs, fmaf(M[5], fys, M[6]));
+        const float az = fmaf(M[8], fxs, fmaf(M[9], fys, M[10]));
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const float X = fmaf(ax, dep[i], M[3]), Y = fmaf(ay, dep[i], M[7]), Z = fmaf(az, dep[i], M[11]);
+            const float rz = __builtin_amdgcn_rcpf(Z);
+            const float ix = fminf(fmaxf(fmaf(X * rz, sx, -0.5f), -1.0f), xhi);
+            const float iy = fminf(fmaxf(fmaf(Y * rz, sy, -0.5f), -1.0f), yhi);
+            const float xf = floorf(ix), yf = floorf(iy);
+            const float wx = ix - xf, wy = iy - yf;
+            float4 f00, f10, f01, f11;
+            if (cur.staged) {
+                const int xi = (int)xf + 1 - cur.x0, yi = (int)yf + 1 - cur.y0;
+                const int xa = min(max(xi, 0), cur.rw - 1), xb = min(max(xi + 1, 0), cur.rw - 1);
+                const int ya = min(max(yi, 0), cur.rh - 1), yb = min(max(yi + 1, 0), cur.rh - 1);
+                const int ra = ya * ROWQ + q, rb = yb * ROWQ + q;
+                f00 = reg[ra + xa * Q];
+                f10 = reg[ra + xb * Q];
+                f01 = reg[rb + xa * Q];
+                f11 = reg[rb + xb * Q];
+            } else {
+                const unsigned off = rowb + PIX + (unsigned)q * 16 + (unsigned)((int)yf * W2 + (int)xf) * PIX;
+                const u32x4 a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+                const u32x4 a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + PIX, 0, 0);
+                const u32x4 a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + rowb, 0, 0);
+                const u32x4 a3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + rowb + PIX, 0, 0);
+                f00 = make_float4(__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z), __uint_as_float(a0.w));
+                f10 = make_float4(__uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z), __uint_as_float(a1.w));
+                f01 = make_float4(__uint_as_float(a2.x), __uint_as_float(a2.y), __uint_as_float(a2.z), __uint_as_float(a2.w));
+                f11 = make_float4(__uint_as_float(a3.x), __uint_as_float(a3.y), __uint_as_float(a3.z), __uint_as_float(a3.w));
+            }
+            const float ux = 1.0f - wx, uy = 1.0f - wy;
+            const float w00 = ux * uy, w10 = wx * uy, w01 = ux * wy, w11 = wx * wy;
+            float4 acc;  // same accumulation order as the direct kernel (bit-identical results)
+            acc.x = fmaf(f11.x, w11, fmaf(f01.x, w01, fmaf(f10.x, w10, fmaf(f00.x, w00, 0.0f))));
+            acc.y = fmaf(f11.y, w11, fmaf(f01.y, w01, fmaf(f10.y, w10, fmaf(f00.y, w00, 0.0f))));
+            acc.z = fmaf(f11.z, w11, fmaf(f01.z, w01, fmaf(f10.z, w10, fmaf(f00.z, w00, 0.0f))));
+            acc.w = fmaf(f11.w, w11, fmaf(f01.w, w01, fmaf(f10.w, w10, fmaf(f00.w, w00, 0.0f))));
+            s1[i].x += acc.x; s1[i].y += acc.y; s1[i].z += acc.z; s1[i].w += acc.w;
+            s2[i].x = fmaf(acc.x, acc.x, s2[i].x); s2[i].y = fmaf(acc.y, acc.y, s2[i].y);
+            s2[i].z = fmaf(acc.z, acc.z, s2[i].z); s2[i].w = fmaf(acc.w, acc.w, s2[i].w);
+        }
+        cur = nxt;
+    }
+
+    const float inv_nv = 1.0f / (float)(p.V + 1);
+    const int y = y0 + ly, x = x0 + lx;
+    if (y < h && x < w) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int d = d0 + i;
+            if (d >= D) break;
+            const float mx = s1[i].x * inv_nv, my = s1[i].y * inv_nv, mz = s1[i].z * inv_nv, mw = s1[i].w * inv_nv;
+            const float4 r = make_float4(fmaf(s2[i].x, inv_nv, -mx * mx), fmaf(s2[i].y, inv_nv, -my * my),
+                                         fmaf(s2[i].z, inv_nv, -mz * mz), fmaf(s2[i].w, inv_nv, -mw * mw));
+            *reinterpret_cast<float4*>(p.out + ((((size_t)b * D + d) * h + y) * w + x) * C + q * 4) = r;
+        }
+    }
+}
+
+static int launch_warp_wave(const WarpParams& p0, hipStream_t st, int nd) {
+    WarpParams p = p0;
+    p.tiles_x = (p.w + 15) / 16;  // groups of 4 wave tiles (16 x 2 pixels)
+    p.tiles_y = (p.h + 1) / 2;
+    const long long groups = (long long)p.tiles_x * p.tiles_y;
+    p.tiles_per_xcd = (int)((groups + 7) / 8);
+    const long long nblk = 8LL * p.tiles_per_xcd * ((p.D + nd - 1) / nd) * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("warp_variance: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    const size_t lds = (size_t)4 * 2 * 4 * 128 * sizeof(float4);
+    timing_begin(st);
+    switch (nd) {
+#define MVD_W(ND)                                                                                                  \
+    case ND:                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)warp_variance_wave_kernel<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(warp_variance_wave_kernel<ND>, dim3((unsigned)nblk), dim3(256), lds, st, p);            \
+        break;
+        MVD_W(4) MVD_W(8)
+#undef MVD_W
+        default:
+            set_error("warp_variance: MVD_K3_CFG wave,%d is not a compiled variant", nd);
+            return MVD_ERR_INVALID_ARG;
+    }
+    timing_end(st);
+    return launch_status("warp_variance_wave");
+}
+
 static int launch_warp_lds(const WarpParams& p0, hipStream_t st, int nd) {
     WarpParams p = p0;
     p.tiles_x = (p.w + 7) / 8;
@@ -644,12 +866,17 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
     p.exact_grid = (layout & MVD_GRID_EXACT) ? 1 : 0;
     if (!warp_only && C == 32 && p.layout == MVD_LAYOUT_NDHWC && !p.exact_grid) {
         // MVD_K3_CFG="lds,nd" selects the LDS-staged form (experiments)
-        if (const char* e = getenv("MVD_K3_CFG"))
+        if (const char* e = getenv("MVD_K3_CFG")) {
             if (e[0] == 'l') {
                 int nd = 4;
                 sscanf(e, "lds,%d", &nd);
                 return launch_warp_lds(p, st, nd);
+            } else if (e[0] == 'w') {
+                int nd = 8;
+                sscanf(e, "wave,%d", &nd);
+                return launch_warp_wave(p, st, nd);
             }
+        }
     }
     return warp_only ? launch_warp<true>(p, C, st) : launch_warp<false>(p, C, st);
 }
