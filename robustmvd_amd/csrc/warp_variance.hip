@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
     float dep[DPB];
 #pragma unroll
     for (int i = 0; i < DPB; ++i) dep[i] = dvals[min(d0 + i, D - 1)];
+    const float mydep = dvals[min(d0 + (q & 3), D - 1)];  // the plane this lane locates for its quad (DPB == 4)
 
     for (int v = 0; v < p.V; ++v) {
         const float* __restrict__ M = p.M + ((size_t)v * p.B + b) * 12;  // wave-uniform: scalar loads
@@ -158,34 +159,62 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
             const_cast<char*>(reinterpret_cast<const char*>(p.src.p[v]) + (size_t)b * img_bytes), 0, (int)img_bytes,
             0x00020000);
         unsigned off[DPB];
-        float wx[DPB], wy[DPB];
-        bool moved[DPB];  // REUSE: the 2x2 source cell of plane i differs from plane i-1's
-#pragma unroll
-        for (int i = 0; i < DPB; ++i) {
+        float wt[DPB][4];  // bilinear weights of the taps nw, ne, sw, se
+        bool moved[DPB];   // REUSE: the 2x2 source cell of plane i differs from plane i-1's
+        // position of one plane: clamp into the zero border (a sample outside the image lands on zero taps; NaN from
+        // Z == 0 clamps to -1), split into cell and fraction
+        auto locate = [&](float depth, float& fwx, float& fwy, unsigned& pixoff) {
             float ix, iy;
             if (p.exact_grid) {
                 // the reference's own chain, one rounding per step: R @ (x*d, y*d, d) + T (utils.py:246-250), perspective
                 // divide, /((W-1)/2) - 1 (:256-257), grid_sample's ((g+1)*W-1)/2
-                const float gx = fx * dep[i], gy = fy * dep[i];
-                const float X = ((M[0] * gx + M[1] * gy) + M[2] * dep[i]) + tx;
-                const float Y = ((M[4] * gx + M[5] * gy) + M[6] * dep[i]) + ty;
-                const float Z = ((M[8] * gx + M[9] * gy) + M[10] * dep[i]) + tz;
+                const float gx = fx * depth, gy = fy * depth;
+                const float X = ((M[0] * gx + M[1] * gy) + M[2] * depth) + tx;
+                const float Y = ((M[4] * gx + M[5] * gy) + M[6] * depth) + ty;
+                const float Z = ((M[8] * gx + M[9] * gy) + M[10] * depth) + tz;
                 ix = unnormalize_coord((X / Z) / half_w - 1.0f, xhi);
                 iy = unnormalize_coord((Y / Z) / half_h - 1.0f, yhi);
             } else {
-                const float X = fmaf(ax, dep[i], tx), Y = fmaf(ay, dep[i], ty), Z = fmaf(az, dep[i], tz);
+                const float X = fmaf(ax, depth, tx), Y = fmaf(ay, depth, ty), Z = fmaf(az, depth, tz);
                 const float rz = __builtin_amdgcn_rcpf(Z);
                 ix = fmaf(X * rz, sx, -0.5f);
                 iy = fmaf(Y * rz, sy, -0.5f);
             }
-            // clamp into the zero border: a sample outside the image lands on zero taps; NaN (Z == 0) clamps to -1
             ix = fminf(fmaxf(ix, -1.0f), xhi);
             iy = fminf(fmaxf(iy, -1.0f), yhi);
             const float xf = floorf(ix), yf = floorf(iy);
-            wx[i] = ix - xf;
-            wy[i] = iy - yf;
-            off[i] = org + (unsigned)((int)yf * W2 + (int)xf) * PIX;  // (yf+1, xf+1) in the padded image
-            moved[i] = i == 0 || off[i] != off[i - 1];
+            fwx = ix - xf;
+            fwy = iy - yf;
+            pixoff = (unsigned)((int)yf * W2 + (int)xf) * PIX;  // (yf+1, xf+1) in the padded image once `org` is added
+        };
+        if constexpr (DPB == 4 && LPP % 4 == 0) {
+            // the LPP lanes of a pixel would each repeat this arithmetic for all 4 planes; instead lane (q & 3) of every
+            // quad does plane (q & 3) and the quad exchanges the three results with DPP quad_perm broadcasts
+            float mwx, mwy;
+            unsigned mpo;
+            locate(mydep, mwx, mwy, mpo);
+            const float mux = 1.0f - mwx, muy = 1.0f - mwy;
+            const float m00 = mux * muy, m10 = mwx * muy, m01 = mux * mwy, m11 = mwx * mwy;
+#define MVD_QB(V, I) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(V), (I) * 0x55, 0xf, 0xf, true))
+#define MVD_QUAD_BCAST(I)                                                                                          \
+    wt[I][0] = MVD_QB(m00, I); wt[I][1] = MVD_QB(m10, I); wt[I][2] = MVD_QB(m01, I); wt[I][3] = MVD_QB(m11, I);     \
+    off[I] = org + (unsigned)__builtin_amdgcn_mov_dpp((int)mpo, (I) * 0x55, 0xf, 0xf, true);  /* quad_perm:[I,I,I,I] */
+            MVD_QUAD_BCAST(0) MVD_QUAD_BCAST(1) MVD_QUAD_BCAST(2) MVD_QUAD_BCAST(3)
+#undef MVD_QUAD_BCAST
+#undef MVD_QB
+#pragma unroll
+            for (int i = 0; i < 4; ++i) moved[i] = i == 0 || off[i] != off[i - 1];
+        } else {
+#pragma unroll
+            for (int i = 0; i < DPB; ++i) {
+                unsigned po;
+                float fwx, fwy;
+                locate(dep[i], fwx, fwy, po);
+                const float ux = 1.0f - fwx, uy = 1.0f - fwy;
+                wt[i][0] = ux * uy; wt[i][1] = fwx * uy; wt[i][2] = ux * fwy; wt[i][3] = fwx * fwy;
+                off[i] = org + po;
+                moved[i] = i == 0 || off[i] != off[i - 1];
+            }
         }
         u32x4 f[DPB][4];
         if constexpr (REUSE) {
@@ -221,15 +250,13 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
         }
 #pragma unroll
         for (int i = 0; i < DPB; ++i) {
-            const float ux = 1.0f - wx[i], uy = 1.0f - wy[i];
-            const float wt[4] = {ux * uy, wx[i] * uy, ux * wy[i], wx[i] * wy[i]};
             float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                acc.x = fmaf(__uint_as_float(f[i][k].x), wt[k], acc.x);
-                acc.y = fmaf(__uint_as_float(f[i][k].y), wt[k], acc.y);
-                acc.z = fmaf(__uint_as_float(f[i][k].z), wt[k], acc.z);
-                acc.w = fmaf(__uint_as_float(f[i][k].w), wt[k], acc.w);
+                acc.x = fmaf(__uint_as_float(f[i][k].x), wt[i][k], acc.x);
+                acc.y = fmaf(__uint_as_float(f[i][k].y), wt[i][k], acc.y);
+                acc.z = fmaf(__uint_as_float(f[i][k].z), wt[i][k], acc.z);
+                acc.w = fmaf(__uint_as_float(f[i][k].w), wt[i][k], acc.w);
             }
             s1[i].x += acc.x; s1[i].y += acc.y; s1[i].z += acc.z; s1[i].w += acc.w;
             s2[i].x = fmaf(acc.x, acc.x, s2[i].x); s2[i].y = fmaf(acc.y, acc.y, s2[i].y);
