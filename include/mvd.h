@@ -47,6 +47,16 @@ typedef enum {
  * operation chain (IEEE divisions, normalise then un-normalise), rounding for rounding, instead of the default
  * folded form ix = X * rcp(Z) * W/(W-1) - 0.5.  The default is within 1e-4 px of the chain; exact costs ~40 %. */
 #define MVD_GRID_EXACT 0x100
+/* OR into `out_layout` of mvd_warp_variance_f32: key_feat and every src_feat are not (B,C,h,w) maps but already the
+ * zero-bordered channel-last copies (B,h+3,w+3,C) the kernel gathers from (map at rows/cols 1..h / 1..w, zeros around),
+ * as mvd_conv2d_bn_relu_f32 writes them with MVD_LAYOUT_NHWC_BORDER: the re-packing launches are skipped and the
+ * workspace only has to hold the composed transforms (MVD_MAX_VIEWS*B*12 floats, rounded up to 256 bytes). */
+#define MVD_FEAT_NHWC_BORDER 0x200
+
+/* layouts of a 4-D feature map */
+#define MVD_LAYOUT_NCHW 0        /* (B, C, h, w): the reference's */
+#define MVD_LAYOUT_NHWC 1        /* (B, h, w, C): channel-last, between the engine's own 2-D layers */
+#define MVD_LAYOUT_NHWC_BORDER 2 /* (B, h+3, w+3, C): channel-last with the map at (1,1) and zeros around: what K3 gathers from */
 
 int mvd_version(void);
 /* thread-local; valid until the next failing call on this thread */
@@ -131,6 +141,24 @@ int mvd_pack_conv3d_weights_f32(const float* w, int Cin, int Cout, int mode, flo
  * scale, shift (Cout); skip NULL or (B,Do,ho,wo,Cout).  Cin in {8,16,32,64}; Cout in {1,8,16,32,64}. */
 int mvd_conv3d_bn_relu_f32(const float* x, const float* packed_w, const float* scale, const float* shift,
                            const float* skip, float* y, int B, int Di, int hi, int wi, int Cin, int Cout, int mode,
+                           int relu, mvd_stream_t stream);
+
+/* K6 — one layer of MVSNet's FeatureNet (rmvd/models/blocks/mvsnet_components.py:44-66; ConvBnReLU :8-22) as an
+ * implicit GEMM on the fp32 matrix cores: Conv2d k x k with padding k/2 (k = 3 stride 1, or k = 5 stride 2), then a
+ * per-channel affine (eval-mode BatchNorm2d folded to scale/shift; scale = 1, shift = bias for the final `feature`
+ * conv) and optional ReLU, in one pass.  Weights must first be packed with mvd_pack_conv2d_weights_f32.
+ *   x   in_layout MVD_LAYOUT_NCHW: (B,3,hi,wi) — the normalised image, Cin must be 3
+ *       in_layout MVD_LAYOUT_NHWC: (B,hi,wi,Cin), Cin in {8,16,32}
+ *   y   out_layout MVD_LAYOUT_NHWC: (B,ho,wo,Cout);  MVD_LAYOUT_NCHW: (B,Cout,ho,wo) (the reference's layout);
+ *       MVD_LAYOUT_NHWC_BORDER: (B,ho+3,wo+3,Cout) with the map at rows/cols 1..ho/1..wo — the zero-bordered layout
+ *       K3 gathers from (mvd_warp_variance_f32 with MVD_FEAT_NHWC_BORDER); the caller zeroes the buffer once, the
+ *       kernel writes only the interior.
+ *   ho = (hi-1)/stride + 1, wo likewise; Cout in {8,16,32}; scale, shift (Cout). */
+size_t mvd_conv2d_packed_weight_floats(int Cin, int Cout, int ksize);
+/* w: Conv2d layout (Cout,Cin,k,k) */
+int mvd_pack_conv2d_weights_f32(const float* w, int Cin, int Cout, int ksize, float* packed, mvd_stream_t stream);
+int mvd_conv2d_bn_relu_f32(const float* x, int in_layout, const float* packed_w, const float* scale, const float* shift,
+                           float* y, int out_layout, int B, int hi, int wi, int Cin, int Cout, int ksize, int stride,
                            int relu, mvd_stream_t stream);
 
 /* K5 — replaces F.softmax + depth_regression + the 4-bin confidence of MVSNet.forward

@@ -25,6 +25,17 @@ def _bn2d(x, sd, p, eps=1e-5):
                         False, 0.0, eps)
 
 
+def conv_bn_relu_2d(x, weight, bn=None, bias=None, stride=1, relu=True, eps=1e-5):
+    """One ConvBnReLU (mvsnet_components.py:8-22) / plain Conv2d on torch CPU, the reference's own arithmetic: conv with
+    padding k/2, eval-mode batch_norm from bn = (weight, bias, running_mean, running_var), ReLU.  x (B,Cin,H,W) numpy."""
+    with torch.no_grad():
+        w = _t(weight)
+        y = F.conv2d(_t(x), w, None if bias is None else _t(bias), stride, w.shape[-1] // 2)
+        if bn is not None:
+            y = F.batch_norm(y, _t(bn[2]), _t(bn[3]), _t(bn[0]), _t(bn[1]), False, 0.0, eps)
+        return (F.relu(y) if relu else y).numpy()
+
+
 def feature_net(x, sd, prefix="feature."):
     """FeatureNet (mvsnet_components.py:44-66) on torch CPU."""
     spec = [(1, 1), (1, 1), (2, 2), (1, 1), (1, 1), (2, 2), (1, 1)]

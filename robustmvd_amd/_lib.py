@@ -15,9 +15,13 @@ MVD_MAX_VIEWS = 16
 LAYOUT_NCDHW = 0
 LAYOUT_NDHWC = 1
 GRID_EXACT = 0x100
+FEAT_NHWC_BORDER = 0x200
 CONV3D_STRIDE1 = 0
 CONV3D_STRIDE2 = 1
 DECONV3D_STRIDE2 = 2
+LAYOUT_NCHW = 0
+LAYOUT_NHWC = 1
+LAYOUT_NHWC_BORDER = 2
 
 _c_float_p = ctypes.c_void_p
 _pp = ctypes.POINTER(ctypes.c_void_p)
@@ -39,6 +43,10 @@ SIGNATURES = {
     "mvd_conv3d_packed_weight_floats": (_sz, [_i, _i]),
     "mvd_pack_conv3d_weights_f32": (_i, [_c_float_p, _i, _i, _i, _c_float_p, ctypes.c_void_p]),
     "mvd_conv3d_bn_relu_f32": (_i, [_c_float_p] * 6 + [_i] * 8 + [ctypes.c_void_p]),
+    "mvd_conv2d_packed_weight_floats": (_sz, [_i, _i, _i]),
+    "mvd_pack_conv2d_weights_f32": (_i, [_c_float_p, _i, _i, _i, _c_float_p, ctypes.c_void_p]),
+    "mvd_conv2d_bn_relu_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _i] + [_i] * 8
+                               + [ctypes.c_void_p]),
     "mvd_softmax_regress_f32": (_i, [_c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "mvd_arm_kernel_timing": (_i, [ctypes.c_void_p, ctypes.c_void_p]),
     "mvd_nchw_to_nhwc_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),

@@ -7,8 +7,9 @@ state-dict keys; their forward passes run on the HIP 
   CostRegNet              rmvd/models/blocks/mvsnet_components.py:69-123  -> K4 mvd_conv3d_bn_relu_f32 x 11
   depth_regression        rmvd/models/blocks/utils.py:271-274             (plain expectation; the fused K5 is ops.softmax_regress)
 
-The 2-D CNNs next to the path (DispNet encoder/decoder, MVSNet FeatureNet) are ordinary torch modules
-that run on MIOpen; they are not part of the hand-written path.
+  FeatureNet              rmvd/models/blocks/mvsnet_components.py:44-66   -> K6 mvd_conv2d_bn_relu_f32 x 8
+
+The DispNet encoder/decoder 2-D CNN around the Path-A sweep is an ordinary torch module that runs on MIOpen.
 """
 import numpy as np
 import torch
@@ -116,22 +117,58 @@ class ConvBnReLU(nn.Module):
         return F.relu(self.bn(self.conv(x)), inplace=True)
 
 
+def fold_bn(bn):
+    """Eval-mode BatchNorm as a per-channel scale/shift."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return scale.detach().contiguous(), (bn.bias - bn.running_mean * scale).detach().contiguous()
+
+
 class FeatureNet(nn.Module):
-    """2-D feature pyramid of MVSNet (mvsnet_components.py:44-66); runs on MIOpen."""
+    """2-D feature pyramid of MVSNet (mvsnet_components.py:44-66).  Parameters live in ordinary nn.Conv2d /
+    nn.BatchNorm2d modules (the reference's checkpoints load); forward folds BN (eval mode) and runs 8 fused HIP
+    layers (K6, ops.conv2d_bn_relu) on channel-last activations."""
+
+    SPEC = [(3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1), (16, 16, 3, 1, 1),
+            (16, 32, 5, 2, 2), (32, 32, 3, 1, 1)]
 
     def __init__(self):
         super().__init__()
         self.inplanes = 32
-        spec = [(3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1), (16, 16, 3, 1, 1),
-                (16, 32, 5, 2, 2), (32, 32, 3, 1, 1)]
-        for i, s in enumerate(spec):
+        for i, s in enumerate(self.SPEC):
             setattr(self, f"conv{i}", ConvBnReLU(*s))
         self.feature = nn.Conv2d(32, 32, 3, 1, 1)
+        self._packed = None
+        self._packed_key = None
+
+    def _prepare(self):
+        """Packs weights into MFMA fragment order and folds BN; cached until a parameter changes."""
+        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        if self.training:
+            raise RuntimeError("FeatureNet HIP path folds BatchNorm running statistics: call .eval() first")
+        pk = []
+        for i, (cin, cout, k, stride, _) in enumerate(self.SPEC):
+            m = getattr(self, f"conv{i}")
+            w, _, _, _ = ops.pack_conv2d_weights(m.conv.weight.detach())
+            pk.append((w, cin, cout, k, stride, *fold_bn(m.bn), True))
+        w, _, _, _ = ops.pack_conv2d_weights(self.feature.weight.detach())
+        pk.append((w, 32, 32, 3, 1, torch.ones(32, device=w.device), self.feature.bias.detach().contiguous(), False))
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    @torch.no_grad()
+    def forward_layout(self, x, out_layout):
+        """x (N,3,H,W) normalised images -> features at H/4 x W/4 in `out_layout` (L.LAYOUT_*)."""
+        pk = self._prepare()
+        for i, (w, cin, cout, k, stride, scale, shift, relu) in enumerate(pk):
+            x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu,
+                                   out_layout=out_layout if i == len(pk) - 1 else L.LAYOUT_NHWC)
+        return x
 
     def forward(self, x):
-        for i in range(7):
-            x = getattr(self, f"conv{i}")(x)
-        return self.feature(x)
+        """Reference layout: (N,3,H,W) -> (N,32,H/4,W/4)."""
+        return self.forward_layout(x, L.LAYOUT_NCHW)
 
 
 class ConvBnReLU3D(nn.Module):
@@ -165,11 +202,6 @@ class CostRegNet(nn.Module):
         self._packed = None
         self._packed_key = None
 
-    @staticmethod
-    def _fold(bn):
-        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-        return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
-
     def _prepare(self):
         """Packs weights into MFMA fragment order and folds BN; cached until a parameter changes."""
         key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
@@ -182,11 +214,11 @@ class CostRegNet(nn.Module):
             m = getattr(self, name)
             mode = L.CONV3D_STRIDE1 if stride == 1 else L.CONV3D_STRIDE2
             w, _, _ = ops.pack_conv3d_weights(m.conv.weight.detach(), mode)
-            pk[name] = (w, cin, cout, *self._fold(m.bn), mode)
+            pk[name] = (w, cin, cout, *fold_bn(m.bn), mode)
         for name, cin, cout in self.UPS:
             m = getattr(self, name)
             w, _, _ = ops.pack_conv3d_weights(m[0].weight.detach(), L.DECONV3D_STRIDE2)
-            pk[name] = (w, cin, cout, *self._fold(m[1]), L.DECONV3D_STRIDE2)
+            pk[name] = (w, cin, cout, *fold_bn(m[1]), L.DECONV3D_STRIDE2)
         w, _, _ = ops.pack_conv3d_weights(self.prob.weight.detach(), L.CONV3D_STRIDE1)
         pk["prob"] = (w, 8, 1, torch.ones(1, device=w.device), self.prob.bias.detach().contiguous(), L.CONV3D_STRIDE1)
         self._packed, self._packed_key = pk, key

@@ -856,7 +856,11 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
     MVD_REQUIRE(C == 4 || C == 8 || C == 16 || C == 32 || C == 64, "%s: C=%d unsupported (need 4, 8, 16, 32 or 64)", who, C);
     MVD_REQUIRE((long long)(h + 3) * (w + 3) * C * 4 < 0x7fffffffLL && h < (1 << 23) && w < (1 << 23),
                 "%s: one padded feature map of %dx%dx%d floats exceeds the 2 GiB buffer-offset range", who, h, w, C);
-    const size_t need = mvd_warp_variance_workspace_bytes(B, C, h, w, warp_only ? 0 : V);
+    // MVD_FEAT_NHWC_BORDER: the caller's maps already are zero-bordered channel-last copies (K6 writes them); only the
+    // composed transforms need workspace
+    const bool staged = (layout & MVD_FEAT_NHWC_BORDER) != 0;
+    const size_t need = staged ? align_up((size_t)MVD_MAX_VIEWS * B * 12 * sizeof(float), 256)
+                               : mvd_warp_variance_workspace_bytes(B, C, h, w, warp_only ? 0 : V);
     if (!workspace || workspace_bytes < need) {
         set_error("%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
         return MVD_ERR_WORKSPACE;
@@ -868,18 +872,26 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
     ws += align_up((size_t)MVD_MAX_VIEWS * B * 12 * sizeof(float), 256);
     int rc;
     if (!warp_only) {
-        rc = repack_padded(key_feat, (float*)ws, B, C, h, w, st);
-        if (rc) return rc;
-        p.key = (float*)ws;
-        ws += slot;
+        if (staged) {
+            p.key = key_feat;
+        } else {
+            rc = repack_padded(key_feat, (float*)ws, B, C, h, w, st);
+            if (rc) return rc;
+            p.key = (float*)ws;
+            ws += slot;
+        }
     }
     for (int v = 0; v < V; ++v) {
         MVD_REQUIRE(src_feat[v] && src_proj[v], "%s: NULL view %d", who, v);
-        rc = repack_padded(src_feat[v], (float*)ws, B, C, h, w, st);
-        if (rc) return rc;
-        p.src.p[v] = (float*)ws;
+        if (staged) {
+            p.src.p[v] = src_feat[v];
+        } else {
+            rc = repack_padded(src_feat[v], (float*)ws, B, C, h, w, st);
+            if (rc) return rc;
+            p.src.p[v] = (float*)ws;
+            ws += slot;
+        }
         p.proj.p[v] = src_proj[v];
-        ws += slot;
     }
     hipLaunchKernelGGL(compose_transforms_kernel, dim3((unsigned)((V * B * 12 + 255) / 256)), dim3(256), 0, st, p.proj,
                        key_proj_inv, B, V, const_cast<float*>(p.M));

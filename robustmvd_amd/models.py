@@ -10,6 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib as L
 from . import ops
 from .blocks import (CostRegNet, DispnetContextEncoder, DispnetCostvolumeEncoder, DispnetDecoder, DispnetEncoder,
                      FeatureNet, LearnedFusion, PlanesweepCorrelation)
@@ -175,9 +176,10 @@ class MVSNet(nn.Module):
         views = [select_by_index(images, kidx)] + exclude_index(images, kidx)
         projs = [select_by_index(proj, kidx)] + exclude_index(proj, kidx)
 
-        feats = self.feature(torch.cat(views, 0))           # (V*B, 32, h, w) on MIOpen
+        # K6 x 8: ((V+1)*B, h+3, w+3, 32), the last layer writing straight into K3's zero-bordered staging layout
+        feats = self.feature.forward_layout(torch.cat(views, 0), L.LAYOUT_NHWC_BORDER)
         feats = list(torch.split(feats, n, 0))
-        var = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True)   # K3
+        var = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True, staged=True)  # K3
         cost = self.cost_regularization.forward_channels_last(var)                                              # K4
         del var
         depth, conf = ops.softmax_regress(cost, depth_samples)                                                  # K5

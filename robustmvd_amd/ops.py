@@ -83,17 +83,23 @@ def fuse_views(corrs, masks, scores):
 
 
 @torch.no_grad()
-def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, channels_last=False, exact_grid=False):
+def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, channels_last=False, exact_grid=False,
+                  staged=False):
     """K3. key_feat (B,C,h,w); src_feats V x (B,C,h,w); src_projs V x (B,4,4); key_proj_inv (B,4,4);
     depth_values (B,D).  Returns the variance volume (B,C,D,h,w), or (B,D,h,w,C) if channels_last.
-    exact_grid: sampling positions follow the reference's operation chain rounding for rounding (MVD_GRID_EXACT)."""
+    exact_grid: sampling positions follow the reference's operation chain rounding for rounding (MVD_GRID_EXACT).
+    staged: the feature maps are the zero-bordered channel-last (B,h+3,w+3,C) copies K6 writes
+    (conv2d_bn_relu(..., out_layout=LAYOUT_NHWC_BORDER)); the re-packing launches are skipped (MVD_FEAT_NHWC_BORDER)."""
     lib = L.load()
     kf = L.as_f32(key_feat, "key_feat")
     if kf.dim() != 4:
-        raise ValueError("key_feat must be (B,C,h,w)")
-    B, C, h, w = kf.shape
+        raise ValueError("key_feat must be (B,C,h,w)" + (" / (B,h+3,w+3,C) when staged" if staged else ""))
+    if staged:
+        B, h, w, C = kf.shape[0], kf.shape[1] - 3, kf.shape[2] - 3, kf.shape[3]
+    else:
+        B, C, h, w = kf.shape
     dev = kf.device
-    srcs = [L.as_f32(s, f"src_feats[{i}]", (B, C, h, w), dev) for i, s in enumerate(_views(src_feats, "src_feats"))]
+    srcs = [L.as_f32(s, f"src_feats[{i}]", tuple(kf.shape), dev) for i, s in enumerate(_views(src_feats, "src_feats"))]
     V = len(srcs)
     projs = [L.as_f32(p, f"src_projs[{i}]", (B, 4, 4), dev) for i, p in enumerate(_views(src_projs, "src_projs", V))]
     kpi = L.as_f32(key_proj_inv, "key_proj_inv", (B, 4, 4), dev)
@@ -105,15 +111,15 @@ def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, ch
         raise ValueError(f"feature channels C={C} unsupported (4, 8, 16, 32, 64)")
     shape = (B, D, h, w, C) if channels_last else (B, C, D, h, w)
     out = torch.empty(shape, dtype=torch.float32, device=dev)
-    wsb = lib.mvd_warp_variance_workspace_bytes(B, C, h, w, V)
+    wsb = lib.mvd_warp_variance_workspace_bytes(B, C, h, w, 0 if staged else V)
     wsp = _workspace(wsb, dev)
     a_s, k1 = L.ptr_array(srcs)
     a_p, k2 = L.ptr_array(projs)
+    flags = (L.LAYOUT_NDHWC if channels_last else L.LAYOUT_NCDHW) | (L.GRID_EXACT if exact_grid else 0) | \
+        (L.FEAT_NHWC_BORDER if staged else 0)
     with torch.cuda.device(dev):
-        rc = lib.mvd_warp_variance_f32(L.ptr(kf), a_s, a_p, L.ptr(kpi), L.ptr(dv), B, C, D, h, w, V, L.ptr(out),
-                                       (L.LAYOUT_NDHWC if channels_last else L.LAYOUT_NCDHW) | (L.GRID_EXACT if exact_grid else 0),
-                                       L.ptr(wsp), wsb,
-                                       L.stream_of(kf))
+        rc = lib.mvd_warp_variance_f32(L.ptr(kf), a_s, a_p, L.ptr(kpi), L.ptr(dv), B, C, D, h, w, V, L.ptr(out), flags,
+                                       L.ptr(wsp), wsb, L.stream_of(kf))
     L.check(rc, "mvd_warp_variance_f32")
     return out
 
@@ -194,6 +200,66 @@ def conv3d_bn_relu(x, packed, Cin, Cout, scale, shift, mode, relu=True, skip=Non
         rc = lib.mvd_conv3d_bn_relu_f32(L.ptr(x), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(skip), L.ptr(y), B, Di,
                                         hi, wi, Cin, Cout, mode, int(bool(relu)), L.stream_of(x))
     L.check(rc, "mvd_conv3d_bn_relu_f32")
+    return y
+
+
+@torch.no_grad()
+def pack_conv2d_weights(weight):
+    """weight: Conv2d (Cout,Cin,k,k), k in (3, 5) -> (packed, Cin, Cout, k)."""
+    lib = L.load()
+    wt = L.as_f32(weight, "weight")
+    if wt.dim() != 4 or wt.shape[2] != wt.shape[3]:
+        raise ValueError(f"weight must be (Cout,Cin,k,k), got {tuple(wt.shape)}")
+    Cout, Cin, k = wt.shape[0], wt.shape[1], wt.shape[2]
+    n = lib.mvd_conv2d_packed_weight_floats(Cin, Cout, k)
+    if n == 0:
+        raise ValueError(f"conv2d: Cin={Cin}, Cout={Cout}, k={k} unsupported (Cin in 3/8/16/32, Cout in 8/16/32, k in 3/5)")
+    packed = torch.empty(n, dtype=torch.float32, device=wt.device)
+    with torch.cuda.device(wt.device):
+        rc = lib.mvd_pack_conv2d_weights_f32(L.ptr(wt), Cin, Cout, k, L.ptr(packed), L.stream_of(wt))
+    L.check(rc, "mvd_pack_conv2d_weights_f32")
+    return packed, Cin, Cout, k
+
+
+@torch.no_grad()
+def conv2d_bn_relu(x, packed, Cin, Cout, ksize, stride, scale, shift, relu=True, out_layout=L.LAYOUT_NHWC, out=None):
+    """K6. x: (B,3,H,W) image when Cin == 3, else channel-last (B,h,w,Cin).  Returns (B,ho,wo,Cout) for LAYOUT_NHWC,
+    (B,Cout,ho,wo) for LAYOUT_NCHW, or the zero-bordered (B,ho+3,wo+3,Cout) staging map for LAYOUT_NHWC_BORDER
+    (`out` may pass a buffer whose border is already zero; only the interior is written)."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    if Cin == 3:
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"x must be (B,3,H,W), got {tuple(x.shape)}")
+        B, _, hi, wi = x.shape
+        in_layout = L.LAYOUT_NCHW
+    else:
+        if x.dim() != 4 or x.shape[-1] != Cin:
+            raise ValueError(f"x must be (B,h,w,{Cin}) channel-last, got {tuple(x.shape)}")
+        B, hi, wi, _ = x.shape
+        in_layout = L.LAYOUT_NHWC
+    if (ksize, stride) not in ((3, 1), (5, 2)):
+        raise ValueError(f"conv2d: kernel {ksize} stride {stride} unsupported (3/1 or 5/2)")
+    dev = x.device
+    ho, wo = (hi - 1) // stride + 1, (wi - 1) // stride + 1
+    oshape = {L.LAYOUT_NHWC: (B, ho, wo, Cout), L.LAYOUT_NCHW: (B, Cout, ho, wo),
+              L.LAYOUT_NHWC_BORDER: (B, ho + 3, wo + 3, Cout)}.get(out_layout)
+    if oshape is None:
+        raise ValueError(f"out_layout {out_layout}")
+    scale = L.as_f32(scale, "scale", (Cout,), dev)
+    shift = L.as_f32(shift, "shift", (Cout,), dev)
+    if out is not None:
+        y = L.as_f32(out, "out", oshape, dev)
+        if y.data_ptr() != out.data_ptr():
+            raise ValueError("out must be a contiguous fp32 tensor")
+    elif out_layout == L.LAYOUT_NHWC_BORDER:
+        y = torch.zeros(oshape, dtype=torch.float32, device=dev)
+    else:
+        y = torch.empty(oshape, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_conv2d_bn_relu_f32(L.ptr(x), in_layout, L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), out_layout,
+                                        B, hi, wi, Cin, Cout, ksize, stride, int(bool(relu)), L.stream_of(x))
+    L.check(rc, "mvd_conv2d_bn_relu_f32")
     return y
 
 

@@ -15,6 +15,7 @@ Fixture groups:
   g6_regress       softmax + depth_regression + confidence          mvsnet.py:139-160
   g7_robustmvd     RobustMVD end-to-end on sample_data (384x576)    robust_mvd.py:57-99
   g8_mvsnet        MVSNet end-to-end 64x96, D=32, V=2               mvsnet.py:45-168
+  g9_featurenet    FeatureNet (2 images 52x76) + per-layer outputs  mvsnet_components.py:44-66
 """
 import os
 import sys
@@ -238,6 +239,26 @@ def g5():
     save("g5_costreg", weight_seed=500, x_seed=501, out=y, conv0=c0.numpy(), conv1=c1.numpy())
 
 
+def featurenet_shapes():
+    m = ref.mvsnet_components.FeatureNet()
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def g9():
+    sd = gc.fill_state_dict(featurenet_shapes(), 900)
+    m = ref.mvsnet_components.FeatureNet().eval()
+    full = {k: t(v) for k, v in sd.items()}
+    for k, v in m.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            full[k] = v
+    m.load_state_dict(full)
+    x = gc.rng_array(901, (2, 3, 52, 76), 0.5)  # 52x76: ragged against every tile shape, odd sizes after /2 and /4
+    y = m(t(x))
+    c0 = m.conv0(t(x))
+    c2 = m.conv2(m.conv1(c0))
+    save("g9_featurenet", weight_seed=900, x_seed=901, out=y.numpy(), conv0=c0.numpy(), conv2=c2.numpy())
+
+
 def g6():
     out = {}
     for name, (B, D, h, w, seed, scale) in {"a": (2, 32, 16, 24, 600, 3.0), "b": (1, 8, 5, 7, 601, 8.0)}.items():
@@ -325,6 +346,6 @@ def g8():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for g in which:
         globals()[g]()

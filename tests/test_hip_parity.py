@@ -8,7 +8,8 @@ import torch
 
 import gen_common as gc
 from conftest import load_golden, unpack_mask
-from test_oracle_golden import (_sweep_inputs, check_sweep_outputs, costreg_shapes, fusion_inputs, fusion_weights)
+from test_oracle_golden import (_sweep_inputs, check_sweep_outputs, costreg_shapes, featurenet_shapes, fusion_inputs,
+                                fusion_weights)
 
 pytestmark = pytest.mark.gpu
 ATOL = RTOL = 1e-4
@@ -124,6 +125,40 @@ def test_costreg_golden(dev):
     out = net(xt)
     assert tuple(out.shape) == (1, 1, 16, 16, 24)
     np.testing.assert_allclose(out.cpu().numpy(), g["out"], atol=2e-4, rtol=1e-3)
+
+
+def test_featurenet_golden(dev):
+    """K6 x 8 against the reference FeatureNet's outputs (g9): first layer (3-channel image input), the first stride-2
+    layer, and the whole net in the reference's layout and in K3's zero-bordered staging layout."""
+    import robustmvd_amd as R
+    from robustmvd_amd import ops
+    from robustmvd_amd import _lib as L
+    g = load_golden("g9_featurenet")
+    net = R.blocks.FeatureNet().eval()
+    full = net.state_dict()
+    for k, v in gc.fill_state_dict(featurenet_shapes(), int(g["weight_seed"])).items():
+        full[k] = torch.from_numpy(v)
+    net.load_state_dict(full)
+    net = net.to(dev)
+    x = T(gc.rng_array(int(g["x_seed"]), (2, 3, 52, 76), 0.5), dev)
+    pk = net._prepare()
+    w, cin, cout, k, st, sc, sh, relu = pk[0]
+    c0 = ops.conv2d_bn_relu(x, w, cin, cout, k, st, sc, sh, relu=relu)
+    np.testing.assert_allclose(c0.permute(0, 3, 1, 2).cpu().numpy(), g["conv0"], atol=ATOL, rtol=RTOL)
+    w, cin, cout, k, st, sc, sh, relu = pk[1]
+    c1 = ops.conv2d_bn_relu(c0, w, cin, cout, k, st, sc, sh, relu=relu)
+    w, cin, cout, k, st, sc, sh, relu = pk[2]
+    c2 = ops.conv2d_bn_relu(c1, w, cin, cout, k, st, sc, sh, relu=relu)
+    np.testing.assert_allclose(c2.permute(0, 3, 1, 2).cpu().numpy(), g["conv2"], atol=ATOL, rtol=RTOL)
+    out = net(x)
+    assert tuple(out.shape) == (2, 32, 13, 19)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], atol=ATOL, rtol=RTOL)
+    pad = net.forward_layout(x, L.LAYOUT_NHWC_BORDER)
+    assert tuple(pad.shape) == (2, 16, 22, 32)
+    assert torch.equal(pad[:, 1:14, 1:20].permute(0, 3, 1, 2), out)
+    border = pad.clone()
+    border[:, 1:14, 1:20] = 0
+    assert not border.any()
 
 
 def test_channels_last_roundtrip(dev):

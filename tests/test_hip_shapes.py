@@ -161,6 +161,75 @@ def test_conv0_marching_large_grid_vs_oracle(dev):
     np.testing.assert_allclose(yp[..., 0].cpu().numpy(), refp[:, 0], atol=ATOL, rtol=RTOL)
 
 
+@pytest.mark.parametrize("Cin,Cout,k,stride,B,h,w,relu,layout", [
+    (3, 8, 3, 1, 2, 37, 70, True, "nhwc"), (3, 16, 5, 2, 1, 33, 45, True, "nchw"), (3, 32, 3, 1, 1, 9, 130, False, "nhwc"),
+    (8, 8, 3, 1, 1, 40, 64, True, "nhwc"), (8, 16, 5, 2, 2, 38, 66, True, "nhwc"), (8, 32, 5, 2, 1, 21, 35, True, "border"),
+    (16, 16, 3, 1, 1, 17, 65, True, "nchw"), (16, 32, 5, 2, 1, 30, 50, True, "nhwc"), (16, 8, 3, 1, 1, 8, 16, False, "border"),
+    (32, 32, 3, 1, 2, 19, 33, True, "nhwc"), (32, 32, 3, 1, 1, 12, 40, False, "border"), (32, 16, 5, 2, 1, 23, 31, True, "nchw"),
+    (32, 8, 3, 1, 1, 1, 1, True, "nhwc"),
+])
+def test_conv2d_layers_vs_oracle(Cin, Cout, k, stride, B, h, w, relu, layout, dev):
+    """K6: every (Cin, Cout-tile, kernel) kernel family on shapes ragged against the tiles, all three output layouts."""
+    from oracle import pipeline as P
+    from robustmvd_amd import ops
+    from robustmvd_amd import _lib as L
+    rng = np.random.default_rng(Cin * 1000 + Cout * 10 + k)
+    x = rng.standard_normal((B, Cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((Cout, Cin, k, k)) * np.sqrt(2.0 / (Cin * k * k))).astype(np.float32)
+    bn = (rng.uniform(0.5, 1.5, Cout).astype(np.float32), (rng.standard_normal(Cout) * 0.1).astype(np.float32),
+          (rng.standard_normal(Cout) * 0.1).astype(np.float32), rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+    want = P.conv_bn_relu_2d(x, wt, bn, stride=stride, relu=relu)
+    scale = bn[0] / np.sqrt(bn[3] + np.float32(1e-5))
+    shift = bn[1] - bn[2] * scale
+    xt = torch.from_numpy(x).to(dev)
+    packed, _, _, _ = ops.pack_conv2d_weights(torch.from_numpy(wt).to(dev))
+    xin = xt if Cin == 3 else xt.permute(0, 2, 3, 1).contiguous()
+    lay = {"nhwc": L.LAYOUT_NHWC, "nchw": L.LAYOUT_NCHW, "border": L.LAYOUT_NHWC_BORDER}[layout]
+    y = ops.conv2d_bn_relu(xin, packed, Cin, Cout, k, stride, torch.from_numpy(scale).to(dev), torch.from_numpy(shift).to(dev),
+                           relu=relu, out_layout=lay)
+    ho, wo = want.shape[2:]
+    if layout == "nhwc":
+        got = y.permute(0, 3, 1, 2)
+    elif layout == "border":
+        assert tuple(y.shape) == (B, ho + 3, wo + 3, Cout)
+        got = y[:, 1:ho + 1, 1:wo + 1].permute(0, 3, 1, 2)
+        assert float(y.abs().sum()) == pytest.approx(float(got.abs().sum()), rel=1e-6)  # nothing written outside the interior
+    else:
+        got = y
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-4, rtol=1e-4)
+
+
+def test_warp_variance_staged_features_match_repacked(dev):
+    """MVD_FEAT_NHWC_BORDER: handing K3 the zero-bordered channel-last maps gives bit-identical volumes."""
+    from robustmvd_amd import ops
+    B, C, h, w, D, V = 2, 32, 21, 38, 6, 3
+    feats, projs, key_inv, depth = mvs_inputs(B, C, h, w, D, V, seed=77)
+    ft = [T(f, dev) for f in feats]
+    staged = []
+    for f in ft:
+        s_ = torch.zeros(B, h + 3, w + 3, C, device=dev)
+        s_[:, 1:h + 1, 1:w + 1] = f.permute(0, 2, 3, 1)
+        staged.append(s_)
+    args = ([T(p, dev) for p in projs], T(key_inv, dev), T(depth, dev))
+    for cl in (False, True):
+        a = ops.warp_variance(ft[0], ft[1:], *args, channels_last=cl)
+        b = ops.warp_variance(staged[0], staged[1:], *args, channels_last=cl, staged=True)
+        assert torch.equal(a, b)
+
+
+def test_conv2d_rejects_bad_arguments(dev):
+    from robustmvd_amd import ops
+    x = torch.zeros(1, 5, 5, 8, device=dev)
+    with pytest.raises(ValueError):
+        ops.pack_conv2d_weights(torch.zeros(8, 7, 3, 3, device=dev))
+    packed, _, _, _ = ops.pack_conv2d_weights(torch.zeros(8, 8, 3, 3, device=dev))
+    one = torch.ones(8, device=dev)
+    with pytest.raises(ValueError):
+        ops.conv2d_bn_relu(x, packed, 8, 8, 3, 2, one, one)
+    with pytest.raises(ValueError):
+        ops.conv2d_bn_relu(x.permute(0, 3, 1, 2).contiguous(), packed, 8, 8, 3, 1, one, one)
+
+
 @pytest.mark.parametrize("B,D,h,w", [(2, 2, 3, 5), (1, 1, 4, 4), (1, 96, 33, 47)])
 def test_softmax_regress_vs_oracle(B, D, h, w, dev):
     from robustmvd_amd import ops

@@ -122,6 +122,31 @@ def costreg_shapes():
     return s
 
 
+def featurenet_shapes():
+    s = {}
+    for i, (ci, co, k) in enumerate([(3, 8, 3), (8, 8, 3), (8, 16, 5), (16, 16, 3), (16, 16, 3), (16, 32, 5), (32, 32, 3)]):
+        s[f"conv{i}.conv.weight"] = (co, ci, k, k)
+        for p in ("weight", "bias", "running_mean", "running_var"):
+            s[f"conv{i}.bn.{p}"] = (co,)
+    s["feature.weight"] = (32, 32, 3, 3)
+    s["feature.bias"] = (32,)
+    return s
+
+
+def test_g9_featurenet():
+    """The oracle's FeatureNet (torch-CPU layers, oracle/pipeline.py) against the reference module's outputs."""
+    from oracle import pipeline as P
+    g = load_golden("g9_featurenet")
+    sd = gc.fill_state_dict(featurenet_shapes(), int(g["weight_seed"]))
+    x = gc.rng_array(int(g["x_seed"]), (2, 3, 52, 76), 0.5)
+    np.testing.assert_allclose(P.feature_net(x, sd, prefix=""), g["out"], atol=ATOL, rtol=RTOL)
+    bn = lambda i: tuple(sd[f"conv{i}.bn.{p}"] for p in ("weight", "bias", "running_mean", "running_var"))
+    c0 = P.conv_bn_relu_2d(x, sd["conv0.conv.weight"], bn(0))
+    np.testing.assert_allclose(c0, g["conv0"], atol=ATOL, rtol=RTOL)
+    c2 = P.conv_bn_relu_2d(P.conv_bn_relu_2d(c0, sd["conv1.conv.weight"], bn(1)), sd["conv2.conv.weight"], bn(2), stride=2)
+    np.testing.assert_allclose(c2, g["conv2"], atol=ATOL, rtol=RTOL)
+
+
 def test_g5_costreg():
     g = load_golden("g5_costreg")
     sd = gc.fill_state_dict(costreg_shapes(), int(g["weight_seed"]))
