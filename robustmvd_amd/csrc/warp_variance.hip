@@ -79,6 +79,49 @@ __global__ void __launch_bounds__(256) repack_padded_kernel(const float* __restr
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// One plane of one source view: bilinear blend of the cell's 4 taps (4 channels per lane), then the running sum and sum
+// of squares of mvsnet.py:131-134.
+__device__ __forceinline__ void accumulate_cell(float4& a1, float4& a2, const float (&w)[4], const u32x4 (&t)[4]) {
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc.x = fmaf(__uint_as_float(t[k].x), w[k], acc.x);
+        acc.y = fmaf(__uint_as_float(t[k].y), w[k], acc.y);
+        acc.z = fmaf(__uint_as_float(t[k].z), w[k], acc.z);
+        acc.w = fmaf(__uint_as_float(t[k].w), w[k], acc.w);
+    }
+    a1.x += acc.x; a1.y += acc.y; a1.z += acc.z; a1.w += acc.w;
+    a2.x = fmaf(acc.x, acc.x, a2.x); a2.y = fmaf(acc.y, acc.y, a2.y);
+    a2.z = fmaf(acc.z, acc.z, a2.z); a2.w = fmaf(acc.w, acc.w, a2.w);
+}
+
+// The 4 planes of a workgroup for one source view when the WAVE's re-gather pattern is MASK (bit i-1: some lane's
+// 2x2 cell differs between plane i-1 and plane i).  Planes whose bit is clear reuse the previous plane's registers
+// outright — no per-lane select, no exec masking: the texture path charges a gather instruction the same whether 1
+// or 64 lanes are active, so re-gathering for the whole wave costs nothing extra, and a pattern known at compile time
+// lets every load be issued up front and waited for with exact counts.
+template <int MASK>
+__device__ __forceinline__ void gather_blend_4planes(float4 (&s1)[4], float4 (&s2)[4], const float (&wt)[4][4],
+                                                     const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb,
+                                                     unsigned pix) {
+    u32x4 f[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i == 0 || ((MASK >> (i - 1)) & 1)) {
+            f[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
+            f[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + pix, 0, 0);
+            f[i][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb, 0, 0);
+            f[i][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb + pix, 0, 0);
+        }
+    }
+    int src = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i > 0 && ((MASK >> (i - 1)) & 1)) src = i;
+        accumulate_cell(s1[i], s2[i], wt[i], f[src]);
+    }
+}
+
 // Work decomposition (the part that decides where the tap gathers are served from):
 //   * a workgroup owns one row segment of PPB key pixels and DPB consecutive depth planes; for each view
 //     it computes the DPB sample positions, issues all 4*DPB gathers back to back (buffer loads: SGPR
@@ -91,7 +134,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //     with a plane-major grid every XCD streamed all V source images per plane and the gathers were
 //     served by the Infinity Cache (measured 2.8 ms at the headline shape, profiles/r01_*).
 // Placement only affects speed; results do not depend on it.
-template <int LPP, bool WARP_ONLY, int DPB, int MINW, bool REUSE = false>
+template <int LPP, bool WARP_ONLY, int DPB, int MINW, int REUSE = 0>
 __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) {
     constexpr int PPB = 256 / LPP;  // pixels per block
     constexpr int C = LPP * 4;
@@ -127,6 +170,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
     const float xhi = (float)w, yhi = (float)h;
     const float half_w = (float)(w - 1) / 2.0f, half_h = (float)(h - 1) / 2.0f;
     const int W2 = w + 3;
+    const float W2f = (float)W2;
     const unsigned rowb = (unsigned)W2 * PIX;                    // bytes per padded row
     const unsigned img_bytes = (unsigned)(h + 3) * rowb;         // bytes per padded image
     const unsigned org = rowb + PIX + (unsigned)q * 16;          // padded (1,1) + this lane's channel quad
@@ -148,15 +192,29 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
     for (int i = 0; i < DPB; ++i) dep[i] = dvals[min(d0 + i, D - 1)];
     const float mydep = dvals[min(d0 + (q & 3), D - 1)];  // the plane this lane locates for its quad (DPB == 4)
 
+    // the next view's transform and base pointer are fetched (scalar loads) while the current view is processed
+    float Mn[12];
+    const char* srcn;
+    auto fetch_view = [&](int v) {
+        const float* __restrict__ Mv = p.M + ((size_t)v * p.B + b) * 12;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Mn[k] = Mv[k];
+        srcn = reinterpret_cast<const char*>(p.src.p[v]);
+    };
+    fetch_view(0);
     for (int v = 0; v < p.V; ++v) {
-        const float* __restrict__ M = p.M + ((size_t)v * p.B + b) * 12;  // wave-uniform: scalar loads
+        float M[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) M[k] = Mn[k];
+        const char* srcv = srcn;
+        fetch_view(min(v + 1, p.V - 1));
         // (X,Y,Z)(d) = R (x,y,1)^T d + T  (utils.py:246-250)
         const float ax = fmaf(M[0], fx, fmaf(M[1], fy, M[2]));
         const float ay = fmaf(M[4], fx, fmaf(M[5], fy, M[6]));
         const float az = fmaf(M[8], fx, fmaf(M[9], fy, M[10]));
         const float tx = M[3], ty = M[7], tz = M[11];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(p.src.p[v]) + (size_t)b * img_bytes), 0, (int)img_bytes,
+            const_cast<char*>(srcv + (size_t)b * img_bytes), 0, (int)img_bytes,
             0x00020000);
         unsigned off[DPB];
         float wt[DPB][4];  // bilinear weights of the taps nw, ne, sw, se
@@ -180,12 +238,17 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
                 ix = fmaf(X * rz, sx, -0.5f);
                 iy = fmaf(Y * rz, sy, -0.5f);
             }
-            ix = fminf(fmaxf(ix, -1.0f), xhi);
-            iy = fminf(fmaxf(iy, -1.0f), yhi);
+            // v_med3_f32: one instruction; with a NaN operand it returns the minimum of the others, i.e. -1 like
+            // fminf(fmaxf(NaN, -1), hi)
+            ix = __builtin_amdgcn_fmed3f(ix, -1.0f, xhi);
+            iy = __builtin_amdgcn_fmed3f(iy, -1.0f, yhi);
             const float xf = floorf(ix), yf = floorf(iy);
             fwx = ix - xf;
             fwy = iy - yf;
-            pixoff = (unsigned)((int)yf * W2 + (int)xf) * PIX;  // (yf+1, xf+1) in the padded image once `org` is added
+            // (yf+1, xf+1) in the padded image once `org` is added.  With 32 channels the padded map has < 2^24 pixels
+            // (checked on the host), so yf*W2 + xf is exact in fp32 and replaces a quarter-rate integer multiply.
+            if constexpr (LPP == 8) pixoff = (unsigned)(int)fmaf(yf, W2f, xf) * PIX;
+            else pixoff = (unsigned)((int)yf * W2 + (int)xf) * PIX;
         };
         if constexpr (DPB == 4 && LPP % 4 == 0) {
             // the LPP lanes of a pixel would each repeat this arithmetic for all 4 planes; instead lane (q & 3) of every
@@ -216,8 +279,25 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
                 moved[i] = i == 0 || off[i] != off[i - 1];
             }
         }
+        if constexpr (REUSE == 2 && DPB == 4) {
+            // wave-uniform re-gather pattern (see gather_blend_4planes)
+            const unsigned mask = (__builtin_amdgcn_ballot_w64(moved[1]) != 0 ? 1u : 0u) |
+                                  (__builtin_amdgcn_ballot_w64(moved[2]) != 0 ? 2u : 0u) |
+                                  (__builtin_amdgcn_ballot_w64(moved[3]) != 0 ? 4u : 0u);
+            switch (mask) {
+                case 0: gather_blend_4planes<0>(s1, s2, wt, off, rsrc, rowb, PIX); break;
+                case 1: gather_blend_4planes<1>(s1, s2, wt, off, rsrc, rowb, PIX); break;
+                case 2: gather_blend_4planes<2>(s1, s2, wt, off, rsrc, rowb, PIX); break;
+                case 3: gather_blend_4planes<3>(s1, s2, wt, off, rsrc, rowb, PIX); break;
+                case 4: gather_blend_4planes<4>(s1, s2, wt, off, rsrc, rowb, PIX); break;
+                case 5: gather_blend_4planes<5>(s1, s2, wt, off, rsrc, rowb, PIX); break;
+                case 6: gather_blend_4planes<6>(s1, s2, wt, off, rsrc, rowb, PIX); break;
+                default: gather_blend_4planes<7>(s1, s2, wt, off, rsrc, rowb, PIX); break;
+            }
+            continue;
+        }
         u32x4 f[DPB][4];
-        if constexpr (REUSE) {
+        if constexpr (REUSE == 1) {
             // Sweep coherence: from one plane to the next a sample moves a fraction of a pixel, so its 2x2 cell is
             // usually the previous plane's.  Only lanes whose cell moved gather again (exec-masked loads, all issued
             // before the first use); the others take the previous plane's registers.
@@ -765,10 +845,11 @@ static int launch_warp_lds(const WarpParams& p0, hipStream_t st, int nd) {
 // (planes per workgroup, min waves per SIMD) — tuned on MI355X; MVD_K3_CFG="dpb,minw"
 // selects another compiled variant for experiments (C = 32 only).
 static void warp_cfg(int& dpb, int& minw, int& reuse) {
-    dpb = 4; minw = 3; reuse = 1;
+    dpb = 4; minw = 3; reuse = 2;
     if (const char* e = getenv("MVD_K3_CFG")) {
         if (e[0] >= '0' && e[0] <= '9') { sscanf(e, "%d,%d", &dpb, &minw); reuse = 0; }
         if (e[0] == 'r') { sscanf(e, "r%d,%d", &dpb, &minw); reuse = 1; }
+        if (e[0] == 'u') { sscanf(e, "u%d,%d", &dpb, &minw); reuse = 2; }
     }
 }
 
@@ -810,9 +891,10 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
     const dim3 grid((unsigned)nblk);
     timing_begin(st);
 #define MVD_LAUNCH(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW>), grid, dim3(256), 0, st, p)
-#define MVD_LAUNCH_R(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, true>), grid, dim3(256), 0, st, p)
+#define MVD_LAUNCH_R(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, 1>), grid, dim3(256), 0, st, p)
+#define MVD_LAUNCH_U(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, 2>), grid, dim3(256), 0, st, p)
     if (lpp == 8) {
-        switch ((reuse ? 1000 : 0) + dpb * 10 + minw) {
+        switch (reuse * 1000 + dpb * 10 + minw) {
             case 18: MVD_LAUNCH(8, 1, 8); break;
             case 24: MVD_LAUNCH(8, 2, 4); break;
             case 28: MVD_LAUNCH(8, 2, 8); break;
@@ -827,6 +909,9 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
             case 1043: MVD_LAUNCH_R(8, 4, 3); break;
             case 1044: MVD_LAUNCH_R(8, 4, 4); break;
             case 1082: MVD_LAUNCH_R(8, 8, 2); break;
+            case 2042: MVD_LAUNCH_U(8, 4, 2); break;
+            case 2043: MVD_LAUNCH_U(8, 4, 3); break;
+            case 2044: MVD_LAUNCH_U(8, 4, 4); break;
             case 83: MVD_LAUNCH(8, 8, 3); break;
             default:
                 set_error("warp_variance: MVD_K3_CFG=%d,%d is not a compiled variant", dpb, minw);
@@ -842,6 +927,7 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
     }
 #undef MVD_LAUNCH
 #undef MVD_LAUNCH_R
+#undef MVD_LAUNCH_U
     timing_end(st);
     return launch_status("warp_variance");
 }

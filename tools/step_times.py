@@ -29,16 +29,17 @@ with torch.no_grad():
         depth_samples = model.depth_samples(s["depth_range"], n, dev)
         proj = model.projection_matrices(s["intrinsics"], s["poses"], [0], dev)
         e1 = ev()
-        feats = list(torch.split(model.feature(torch.cat(s["images"], 0)), n, 0))
+        from robustmvd_amd import _lib as L
+        feats = list(torch.split(model.feature.forward_layout(torch.cat(s["images"], 0), L.LAYOUT_NHWC_BORDER), n, 0))
         e2 = ev()
-        var = ops.warp_variance(feats[0], feats[1:], proj[1:], proj[0], depth_samples, channels_last=True)
+        var = ops.warp_variance(feats[0], feats[1:], proj[1:], proj[0], depth_samples, channels_last=True, staged=True)
         e3 = ev()
         cost = model.cost_regularization.forward_channels_last(var)
         e4 = ev()
         depth, conf = ops.softmax_regress(cost, depth_samples)
         e5 = ev()
         torch.cuda.synchronize()
-    print("stages ms: prep %.2f  featurenet %.2f  K3(+repack) %.2f  K4 %.2f  K5 %.2f" % (
+    print("stages ms: prep %.2f  featurenet %.2f  K3 %.2f  K4 %.2f  K5 %.2f" % (
         e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3), e3.elapsed_time(e4), e4.elapsed_time(e5)))
 # unsynchronised bursts, like bench.py's timed region
 with torch.no_grad():
