@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmvd_hip.so")
+LIB_PATH = os.environ.get("MVD_LIB_PATH") or os.path.join(_HERE, "lib", "libmvd_hip.so")  # override: kernel experiments
 
 MVD_MAX_VIEWS = 16
 LAYOUT_NCDHW = 0

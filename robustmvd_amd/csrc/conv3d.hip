@@ -67,7 +67,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
                                     int transposed) {
     using G = KGroup<CIN>;
     const bool pair = transposed == 2;  // PAIR mode: taps = (kd, kh, t in 0..3), row = phase * 8 + cout
-    const size_t total = packed_floats<CIN>(NT, pair ? 36 : 27);
+    const bool dpair = transposed == 3;  // transposed conv with 8 output channels: taps = (kd, kh, s in 0..1), row = w-parity * 8 + cout
+    const size_t total = packed_floats<CIN>(NT, pair ? 36 : dpair ? 18 : 27);
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         size_t r = e;
         const int j = r % G::R; r /= G::R;
@@ -83,6 +84,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
             const int t = tap & 3, kdh = tap >> 2;  // kdh = kd * 3 + kh
             const int kw = t - phase;
             if (kw >= 0 && kw <= 2) val = w[((size_t)cout * CIN + cin) * 27 + kdh * 3 + kw];
+        } else if (dpair) {
+            // step s reads input column c + s: s = 0 feeds out[2c] through kw = 1 and out[2c+1] through kw = 2,
+            // s = 1 feeds out[2c+1] through kw = 0 (see deconv3d_pair_kernel)
+            const int pw = row >> 3, cout = row & 7;
+            const int st = tap & 1, kdh = tap >> 1;
+            const int kw = st == 0 ? (pw ? 2 : 1) : (pw ? 0 : -1);
+            if (kw >= 0) val = w[((size_t)cin * 8 + cout) * 27 + kdh * 3 + kw];  // ConvTranspose3d: (Cin,8,3,3,3)
         } else if (row < Cout) {
             val = transposed ? w[((size_t)cin * Cout + row) * 27 + tap]   // ConvTranspose3d: (Cin,Cout,3,3,3)
                              : w[((size_t)row * CIN + cin) * 27 + tap];   // Conv3d: (Cout,Cin,3,3,3)
@@ -668,21 +676,51 @@ __global__ void __launch_bounds__(256) deconv3d_all_kernel(ConvParams p) {
             esh[n][k] = ch < p.Cout ? p.shift[ch] : 0.f;
         }
 
-    // ---- stage input planes zd and zd+1 (zero beyond the volume) ----
+    // weight fragments of the 3 w-taps of one (kd, kh) step in one batch, fetched one step ahead of the MFMAs that use
+    // them (a load + wait per step would expose an L2 round trip nine times per workgroup)
+    auto load_a = [&](int step, float (&dst)[3][G::NKG][NT][G::R]) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int g = 0; g < G::NKG; ++g)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int tap = step * 3 + kw;
+                    const float* wp = p.wpk + ((((size_t)tap * G::NKG + g) * NT + n) * 64 + lane) * G::R;
+                    if constexpr (G::R == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(wp);
+                        dst[kw][g][n][0] = t.x; dst[kw][g][n][1] = t.y; dst[kw][g][n][2] = t.z; dst[kw][g][n][3] = t.w;
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(wp);
+                        dst[kw][g][n][0] = t.x; dst[kw][g][n][1] = t.y;
+                    }
+                }
+    };
+    constexpr bool AHEAD = 2 * 3 * G::NKG * NT * G::R <= 96;  // both batches fit the register file
+    float af[3][G::NKG][NT][G::R];
+    if constexpr (AHEAD) load_a(0, af);
+    // ---- stage input planes zd and zd+1 (zero beyond the volume): all of a thread's loads in flight together ----
     {
-        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(p.x);
+        constexpr int NEL = 2 * ROWS * COLS * C4, NPF = (NEL + 255) / 256;
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(p.x) + (size_t)b * p.Di * p.hi * p.wi * C4;
         float4* __restrict__ s4 = reinterpret_cast<float4*>(slab);
-        for (int r = wave; r < 2 * ROWS; r += 4) {
+        float4 pf[NPF];
+        bool ok[NPF];
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + 256 * i;
+            const int r = e / (COLS * C4), rem = e - r * (COLS * C4);
+            const int col = rem / C4, c4 = rem - col * C4;
             const int pl = r / ROWS, row = r - pl * ROWS;
-            const int plane = zd + pl, gr = r0 + row;
-            const bool ok = plane < p.Di && gr < p.hi;
-            const float4* __restrict__ xr = x4 + (((size_t)b * p.Di + (ok ? plane : 0)) * p.hi + (ok ? gr : 0)) * p.wi * C4;
-            for (int e = lane; e < COLS * C4; e += 64) {
-                const int col = e / C4, c4 = e - col * C4;
-                const int gc = c0 + col;
-                const float4 t = xr[(size_t)min(gc, p.wi - 1) * C4 + c4];
-                s4[((r * COLS + col) * PSTR) / 4 + c4] = (ok && gc < p.wi) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            const int plane = zd + pl, gr = r0 + row, gc = c0 + col;
+            ok[i] = e < NEL && plane < p.Di && gr < p.hi && gc < p.wi;
+            pf[i] = x4[ok[i] ? (((size_t)plane * p.hi + gr) * p.wi + gc) * C4 + c4 : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + 256 * i;
+            const int pix = e / C4, c4 = e - pix * C4;
+            if (e < NEL) s4[(pix * PSTR) / 4 + c4] = ok[i] ? pf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
@@ -696,57 +734,55 @@ __global__ void __launch_bounds__(256) deconv3d_all_kernel(ConvParams p) {
             for (int n = 0; n < NT; ++n) acc[c][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
+    for (int step = 0; step < 9; ++step) {
+        const int kd = step / 3, kh = step % 3;
+        float af_next[3][G::NKG][NT][G::R];
+        if constexpr (AHEAD) {
+            if (step + 1 < 9) load_a(step + 1, af_next);
+        } else {
+            load_a(step, af);
+        }
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            // weight fragments of the 3 w-taps of this (kd, kh) in one batch (one vmcnt wait per 3 taps)
-            float af[3][G::NKG][NT][G::R];
+        for (int kw = 0; kw < 3; ++kw) {
+            const int cls = ((kd != 1) << 2) | ((kh != 1) << 1) | (kw != 1);
+            const float* __restrict__ srow_p =
+                slab + (kd == 0 ? SLAB : 0) + ((wave + (kh == 0)) * COLS + (kw == 0)) * PSTR + G::R * q;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
+            for (int g = 0; g < G::NKG; ++g) {
+                float bf[MT][G::R];
 #pragma unroll
-                for (int g = 0; g < G::NKG; ++g)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const int tap = (kd * 3 + kh) * 3 + kw;
-                        const float* wp = p.wpk + ((((size_t)tap * G::NKG + g) * NT + n) * 64 + lane) * G::R;
-                        if constexpr (G::R == 4) {
-                            const float4 t = *reinterpret_cast<const float4*>(wp);
-                            af[kw][g][n][0] = t.x; af[kw][g][n][1] = t.y; af[kw][g][n][2] = t.z; af[kw][g][n][3] = t.w;
-                        } else {
-                            const float2 t = *reinterpret_cast<const float2*>(wp);
-                            af[kw][g][n][0] = t.x; af[kw][g][n][1] = t.y;
-                        }
+                for (int m = 0; m < MT; ++m) {
+                    const float* bp = srow_p + (m * 16 + vox) * PSTR + g * G::KG;
+                    if constexpr (G::R == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(bp);
+                        bf[m][0] = t.x; bf[m][1] = t.y; bf[m][2] = t.z; bf[m][3] = t.w;
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(bp);
+                        bf[m][0] = t.x; bf[m][1] = t.y;
                     }
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                constexpr int dummy = 0; (void)dummy;
-                const int cls = ((kd != 1) << 2) | ((kh != 1) << 1) | (kw != 1);
-                const float* __restrict__ srow_p =
-                    slab + (kd == 0 ? SLAB : 0) + ((wave + (kh == 0)) * COLS + (kw == 0)) * PSTR + G::R * q;
-#pragma unroll
-                for (int g = 0; g < G::NKG; ++g) {
-                    float bf[MT][G::R];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const float* bp = srow_p + (m * 16 + vox) * PSTR + g * G::KG;
-                        if constexpr (G::R == 4) {
-                            const float4 t = *reinterpret_cast<const float4*>(bp);
-                            bf[m][0] = t.x; bf[m][1] = t.y; bf[m][2] = t.z; bf[m][3] = t.w;
-                        } else {
-                            const float2 t = *reinterpret_cast<const float2*>(bp);
-                            bf[m][0] = t.x; bf[m][1] = t.y;
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < G::R; ++j)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int n = 0; n < NT; ++n)
-                                acc[cls][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kw][g][n][j], bf[m][j], acc[cls][m][n], 0, 0, 0);
                 }
+#pragma unroll
+                for (int j = 0; j < G::R; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[cls][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kw][g][n][j], bf[m][j], acc[cls][m][n], 0, 0, 0);
             }
         }
+        if constexpr (AHEAD) {
+            if (step + 1 < 9) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int g = 0; g < G::NKG; ++g)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int j = 0; j < G::R; ++j) af[kw][g][n][j] = af_next[kw][g][n][j];
+            }
+        }
+    }
 
     // ---- epilogue: 8 classes -> output voxels (2zd+pd, 2row+ph, 2col+pw) ----
     const int arow = r0 + wave;
@@ -777,6 +813,175 @@ __global__ void __launch_bounds__(256) deconv3d_all_kernel(ConvParams p) {
             }
         }
     }
+}
+
+// ConvTranspose3d with 8 output channels (conv11): the 16 MFMA rows are (output w-parity) x (8 couts), so the two
+// w-parity classes of a (d,h)-parity class share one accumulator — 2 MFMA groups per (kd,kh) instead of 3, half the
+// accumulators, and the C/D layout (lane q holds parity q>>1, couts 4(q&1)..+3 of input column `vox`) makes every
+// store a contiguous 1 KiB: 16 column pairs x 64 B.  Weights packed with mode 3 of pack_weights_kernel.
+template <int CIN, int MT>
+__global__ void __launch_bounds__(256) deconv3d_pair_kernel(ConvParams p) {
+    using G = KGroup<CIN>;
+    constexpr int TW = 16 * MT, ROWS = CONV_TH + 1, COLS = TW + 1;
+    constexpr int PSTR = CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR, C4 = CIN / 4;
+    extern __shared__ __attribute__((aligned(16))) float slab[];  // [2 planes][ROWS][COLS][PSTR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int vox = lane & 15, q = lane >> 4;
+    int bx = blockIdx.x;
+    const int tw = bx % p.tiles_w; bx /= p.tiles_w;
+    const int th = bx % p.tiles_h; bx /= p.tiles_h;
+    const int zd = bx % p.Di;
+    const int b = bx / p.Di;
+    const int r0 = th * CONV_TH, c0 = tw * TW;
+
+    float esc[4], esh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        esc[k] = p.scale[(q & 1) * 4 + k];
+        esh[k] = p.shift[(q & 1) * 4 + k];
+    }
+
+    // weight fragments of the 2 steps of one (kd, kh), fetched one (kd, kh) ahead of the MFMAs that use them
+    auto load_a = [&](int kdh, float (&dst)[2][G::NKG][G::R]) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int g = 0; g < G::NKG; ++g) {
+                const float* wp = p.wpk + (((size_t)(kdh * 2 + st) * G::NKG + g) * 64 + lane) * G::R;
+                if constexpr (G::R == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(wp);
+                    dst[st][g][0] = t.x; dst[st][g][1] = t.y; dst[st][g][2] = t.z; dst[st][g][3] = t.w;
+                } else {
+                    const float2 t = *reinterpret_cast<const float2*>(wp);
+                    dst[st][g][0] = t.x; dst[st][g][1] = t.y;
+                }
+            }
+    };
+    float af[2][G::NKG][G::R];
+    load_a(0, af);
+
+    // ---- stage input planes zd and zd+1 (zero beyond the volume): all of a thread's loads in flight together ----
+    {
+        constexpr int NEL = 2 * ROWS * COLS * C4, NPF = (NEL + 255) / 256;
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(p.x) + (size_t)b * p.Di * p.hi * p.wi * C4;
+        float4* __restrict__ s4 = reinterpret_cast<float4*>(slab);
+        float4 pf[NPF];
+        bool ok[NPF];
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + 256 * i;
+            const int r = e / (COLS * C4), rem = e - r * (COLS * C4);
+            const int col = rem / C4, c4 = rem - col * C4;
+            const int pl = r / ROWS, row = r - pl * ROWS;
+            const int plane = zd + pl, gr = r0 + row, gc = c0 + col;
+            ok[i] = e < NEL && plane < p.Di && gr < p.hi && gc < p.wi;
+            pf[i] = x4[ok[i] ? (((size_t)plane * p.hi + gr) * p.wi + gc) * C4 + c4 : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + 256 * i;
+            const int pix = e / C4, c4 = e - pix * C4;
+            if (e < NEL) s4[(pix * PSTR) / 4 + c4] = ok[i] ? pf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[4][MT];  // (d,h)-parity class x column tile
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int kdh = 0; kdh < 9; ++kdh) {
+        const int kd = kdh / 3, kh = kdh % 3;
+        float af_next[2][G::NKG][G::R];
+        if (kdh + 1 < 9) load_a(kdh + 1, af_next);
+        const int cls = ((kd != 1) << 1) | (kh != 1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const float* __restrict__ srow_p = slab + (kd == 0 ? SLAB : 0) + ((wave + (kh == 0)) * COLS + st) * PSTR + G::R * q;
+#pragma unroll
+            for (int g = 0; g < G::NKG; ++g) {
+                float bf[MT][G::R];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float* bp = srow_p + (m * 16 + vox) * PSTR + g * G::KG;
+                    if constexpr (G::R == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(bp);
+                        bf[m][0] = t.x; bf[m][1] = t.y; bf[m][2] = t.z; bf[m][3] = t.w;
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(bp);
+                        bf[m][0] = t.x; bf[m][1] = t.y;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < G::R; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[cls][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st][g][j], bf[m][j], acc[cls][m], 0, 0, 0);
+            }
+        }
+        if (kdh + 1 < 9) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int g = 0; g < G::NKG; ++g)
+#pragma unroll
+                    for (int j = 0; j < G::R; ++j) af[st][g][j] = af_next[st][g][j];
+        }
+    }
+
+    // ---- epilogue: lane (q, vox) owns couts 4(q&1)..+3 of output voxel (2zd+pd, 2row+ph, 2(c0+16m+vox) + (q>>1)) ----
+    const int arow = r0 + wave;
+    if (arow >= p.hi) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int pd = c >> 1, ph = c & 1;
+        const size_t row_base = (((size_t)b * p.Do + 2 * zd + pd) * p.ho + 2 * arow + ph) * p.wo;
+        float4 sk[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int gcol = c0 + m * 16 + vox;
+            sk[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.skip && gcol < p.wi) sk[m] = *reinterpret_cast<const float4*>(p.skip + (row_base + 2 * gcol) * 8 + q * 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int gcol = c0 + m * 16 + vox;
+            if (gcol >= p.wi) continue;
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[k] = fmaf(acc[c][m][k], esc[k], esh[k]);
+                if (p.relu) r[k] = fmaxf(r[k], 0.f);
+            }
+            *reinterpret_cast<float4*>(p.y + (row_base + 2 * gcol) * 8 + q * 4) =
+                make_float4(r[0] + sk[m].x, r[1] + sk[m].y, r[2] + sk[m].z, r[3] + sk[m].w);
+        }
+    }
+}
+
+template <int CIN, int MT>
+static int launch_deconv_pair(const ConvParams& p0, hipStream_t st) {
+    ConvParams p = p0;
+    constexpr size_t lds = (size_t)2 * (CONV_TH + 1) * (16 * MT + 1) * (CIN + CONV_PAD) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "slab exceeds LDS");
+    p.tiles_h = (p.hi + CONV_TH - 1) / CONV_TH;
+    p.tiles_w = (p.wi + 16 * MT - 1) / (16 * MT);
+    const long long nblk = (long long)p.tiles_w * p.tiles_h * p.Di * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    auto kern = deconv3d_pair_kernel<CIN, MT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return launch_status("conv3d: LDS attribute");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    return launch_status("deconv3d_pair");
 }
 
 template <int CIN, int NT, int MT>
@@ -937,6 +1142,36 @@ static int launch_c8_to_1(const ConvParams& p0, hipStream_t st) {
     return launch_status("conv3d_c8_to_1");
 }
 
+// 16-column tiles per wave row, lo..hi: the choice that pads a row of `cols` GEMM columns least (ties: the widest)
+static int best_mt(int cols, int lo, int hi) {
+    int best = hi, waste = 1 << 30;
+    for (int mt = hi; mt >= lo; --mt) {
+        const int tw = 16 * mt, pad = (cols + tw - 1) / tw * tw - cols;
+        if (pad < waste) { waste = pad; best = mt; }
+    }
+    return best;
+}
+
+// the plane-at-a-time kernel with the tile width (MTMAX or one step narrower) that pads the row least
+template <int CIN, int NT, int MTMAX, int MODE>
+static int launch_conv_best(const ConvParams& p, hipStream_t st) {
+    const int gw = MODE == MVD_DECONV3D_STRIDE2 ? p.wi : p.wo;
+    if constexpr (MTMAX >= 4) {
+        if (best_mt(gw, 3, 4) == 3) return launch_conv<CIN, NT, 3, MODE>(p, st);
+    } else if constexpr (MTMAX == 2) {
+        if (best_mt(gw, 1, 2) == 1) return launch_conv<CIN, NT, 1, MODE>(p, st);
+    }
+    return launch_conv<CIN, NT, MTMAX, MODE>(p, st);
+}
+
+template <int CIN, int NT, int MTMAX>
+static int launch_march_best(const ConvParams& p, hipStream_t st) {
+    if constexpr (MTMAX >= 4) {
+        if (best_mt(p.wo, 3, 4) == 3) return launch_march<CIN, NT, 3, false>(p, st);
+    }
+    return launch_march<CIN, NT, MTMAX, false>(p, st);
+}
+
 template <int CIN, int MODE>
 static int dispatch_cout(const ConvParams& p, hipStream_t st) {
     // MT (16-column tiles per wave) chosen so that the slab fits LDS and wide rows get long tiles
@@ -956,9 +1191,9 @@ static int dispatch_cout(const ConvParams& p, hipStream_t st) {
             constexpr int MM = CIN == 16 ? 4 : CIN == 32 ? 2 : 1;
             int rc = -1;
             switch ((p.Cout + 15) / 16) {
-                case 1: rc = launch_march<CIN, 1, MM, false>(p, st); break;
-                case 2: rc = launch_march<CIN, 2, MM, false>(p, st); break;
-                case 4: rc = launch_march<CIN, 4, MM, false>(p, st); break;
+                case 1: rc = launch_march_best<CIN, 1, MM>(p, st); break;
+                case 2: rc = launch_march_best<CIN, 2, MM>(p, st); break;
+                case 4: rc = launch_march_best<CIN, 4, MM>(p, st); break;
             }
             if (rc >= 0) return rc;
         }
@@ -966,15 +1201,26 @@ static int dispatch_cout(const ConvParams& p, hipStream_t st) {
     const int nt = (p.Cout + 15) / 16;
     if constexpr (MODE == MVD_DECONV3D_STRIDE2) {
         // all 8 parity classes per workgroup (Cout a multiple of 4); MVD_K4_DECONV_CLASSES=1 keeps the per-class kernel
+        if (p.Cout == 8) {  // its weights are packed in pair form
+            if constexpr (CIN >= 64) {
+                return launch_deconv_pair<CIN, 2>(p, st);
+            } else {
+                switch (best_mt(p.wi, 2, 4)) {  // fewest padded columns
+                    case 2: return launch_deconv_pair<CIN, 2>(p, st);
+                    case 3: return launch_deconv_pair<CIN, 3>(p, st);
+                    default: return launch_deconv_pair<CIN, 4>(p, st);
+                }
+            }
+        }
         if (p.Cout % 4 == 0 && nt <= 2 && !getenv("MVD_K4_DECONV_CLASSES")) {
             if (nt == 1) return launch_deconv_all<CIN, 1, 2>(p, st);
             return launch_deconv_all<CIN, 2, (CIN >= 64 ? 1 : 2)>(p, st);
         }
     }
     switch (nt) {
-        case 1: return launch_conv<CIN, 1, MT, MODE>(p, st);
-        case 2: return launch_conv<CIN, 2, MT, MODE>(p, st);
-        case 4: return launch_conv<CIN, 4, (MODE == MVD_DECONV3D_STRIDE2 ? 2 : MT), MODE>(p, st);
+        case 1: return launch_conv_best<CIN, 1, MT, MODE>(p, st);
+        case 2: return launch_conv_best<CIN, 2, MT, MODE>(p, st);
+        case 4: return launch_conv_best<CIN, 4, (MODE == MVD_DECONV3D_STRIDE2 ? 2 : MT), MODE>(p, st);
     }
     set_error("conv3d: Cout=%d unsupported", p.Cout);
     return MVD_ERR_INVALID_ARG;
@@ -1000,7 +1246,8 @@ extern "C" {
 
 size_t mvd_conv3d_packed_weight_floats(int Cin, int Cout) {
     if (!mvd::cin_ok(Cin) || !mvd::cout_ok(Cout)) return 0;
-    // 36 taps when a stride-1 layer with 8 output channels is packed for PAIR mode
+    // 36 taps when a stride-1 layer with 8 output channels is packed for PAIR mode (the larger of the forms a
+    // (Cin, Cout) pair can take: the transposed pair form has 18)
     return (size_t)(Cout == 8 ? 36 : 27) * Cin * 16 * ((Cout + 15) / 16);
 }
 
@@ -1010,7 +1257,8 @@ int mvd_pack_conv3d_weights_f32(const float* w, int Cin, int Cout, int mode, flo
     MVD_REQUIRE(mode >= 0 && mode <= 2, "pack_conv3d_weights: mode=%d unknown", mode);
     const int NT = (Cout + 15) / 16;
     // 1: ConvTranspose3d weight layout; 2: PAIR-mode packing (stride-1 conv with 8 output channels)
-    const int tr = mode == MVD_DECONV3D_STRIDE2 ? 1 : (mode == MVD_CONV3D_STRIDE1 && Cout == 8) ? 2 : 0;
+    // 3: transposed conv with 8 output channels, w-parity pair form (deconv3d_pair_kernel)
+    const int tr = mode == MVD_DECONV3D_STRIDE2 ? (Cout == 8 ? 3 : 1) : (mode == MVD_CONV3D_STRIDE1 && Cout == 8) ? 2 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (mode == MVD_CONV3D_STRIDE1 && Cout == 1 && Cin == 8) {  // the vector-ALU `prob` kernel takes [tap][cin]
         hipLaunchKernelGGL(mvd::pack_c8_to_1_kernel, dim3(1), dim3(256), 0, st, w, packed);

@@ -12,6 +12,9 @@
 // Thread mapping: C/4 lanes per output pixel (each lane owns 4 channels = one 16-B load per tap),
 // 256/(C/4) consecutive x pixels per workgroup, one (b, d, y) row segment per workgroup.
 #include "mvd_common.h"
+#ifndef MVD_K3_EXPERIMENT
+#define MVD_K3_EXPERIMENT 0
+#endif
 #include <stdlib.h>
 
 namespace mvd {
@@ -108,10 +111,17 @@ __device__ __forceinline__ void gather_blend_4planes(float4 (&s1)[4], float4 (&s
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i == 0 || ((MASK >> (i - 1)) & 1)) {
+#if MVD_K3_EXPERIMENT == 1 || MVD_K3_EXPERIMENT == 2
+            f[i][0] = u32x4{off[i], off[i] + 1, off[i] + 2, off[i] + 3};
+            f[i][1] = u32x4{off[i] + pix, off[i] + 5, off[i] + 6, off[i] + 7};
+            f[i][2] = u32x4{off[i] + rowb, off[i] + 9, off[i] + 10, off[i] + 11};
+            f[i][3] = u32x4{off[i] + rowb + pix, off[i] + 13, off[i] + 14, off[i] + 15};
+#else
             f[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
             f[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + pix, 0, 0);
             f[i][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb, 0, 0);
             f[i][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + rowb + pix, 0, 0);
+#endif
         }
     }
     int src = 0;
@@ -202,7 +212,12 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
         srcn = reinterpret_cast<const char*>(p.src.p[v]);
     };
     fetch_view(0);
-    for (int v = 0; v < p.V; ++v) {
+#if MVD_K3_EXPERIMENT == 3
+    const int nviews = p.V > 100 ? p.V : 0;
+#else
+    const int nviews = p.V;
+#endif
+    for (int v = 0; v < nviews; ++v) {
         float M[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) M[k] = Mn[k];
@@ -359,7 +374,11 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
                             fmaf(s2[i].z, inv_nv, -mz * mz), fmaf(s2[i].w, inv_nv, -mw * mw));
         }
         if (p.layout == MVD_LAYOUT_NDHWC) {
+#if MVD_K3_EXPERIMENT == 2
+            if (active && r.x == 123.456f)
+#else
             if (active)
+#endif
                 *reinterpret_cast<float4*>(p.out + ((((size_t)b * D + d) * h + y) * w + x) * C + q * 4) = r;
             continue;
         }

@@ -109,6 +109,7 @@ CONV_CASES = [  # (Cin, Cout, mode, D, h, w, relu, skip)
     (64, 64, 0, 3, 5, 17, True, False), (8, 16, 1, 6, 10, 38, True, False), (16, 32, 1, 4, 8, 66, True, False),
     (32, 64, 1, 4, 6, 34, True, False), (64, 32, 2, 2, 3, 9, True, True), (32, 16, 2, 3, 5, 20, True, True),
     (16, 8, 2, 3, 6, 70, True, True), (8, 8, 0, 4, 5, 33, False, False), (16, 8, 0, 4, 5, 33, True, False),
+    (32, 8, 2, 2, 5, 33, False, False), (64, 8, 2, 2, 3, 17, True, True), (8, 8, 2, 3, 4, 65, True, False),
 ]
 
 
