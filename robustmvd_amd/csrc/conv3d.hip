@@ -30,6 +30,7 @@
 namespace mvd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CONV_TH = 4;
 constexpr int CONV_PAD = 4;  // floats of padding per LDS pixel (keeps 16-B alignment, spreads banks)
@@ -1008,11 +1009,12 @@ static int launch_deconv_all(const ConvParams& p0, hipStream_t st) {
 // the matrix cores, so this layer runs on the vector ALU: one lane per output voxel, the three input planes
 // of a 4 x 64 tile resident in LDS (48-B pixels: conflict-free ds_read_b128 across consecutive columns), the
 // 216 weights through the scalar cache.  packed weights here are [tap 27][cin 8].
-__global__ void __launch_bounds__(256) conv3d_c8_to_1_kernel(ConvParams p) {
+constexpr int C8_DZ = 16;  // output planes a workgroup of the 8 -> 1 kernel walks
+__global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
     // depth-marching like conv3d_march_kernel: 3 input planes of the 4 x 64 tile in an LDS ring, the next plane
     // prefetched into registers while the current output plane is computed
     constexpr int CIN = 8, TW = 64, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR;
-    constexpr int NEL = ROWS * COLS * 2, NPF = (NEL + 255) / 256, DZ = 16;
+    constexpr int NEL = ROWS * COLS * 2, NPF = (NEL + 255) / 256, DZ = C8_DZ;
     __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 216 + 4];  // 57 KB + the weights + dummy slot
     // the 216 weights sit in LDS (broadcast reads): scalar-cache loads inside the tap loop would share lgkmcnt
     // with the ds_reads and, returning out of order, force a full drain per tap
@@ -1072,23 +1074,27 @@ __global__ void __launch_bounds__(256) conv3d_c8_to_1_kernel(ConvParams p) {
         store_plane((z + 1) % 3);
         __syncthreads();
         if (z + 1 < z1) load_plane(z + 2);
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;  // four independent FMA chains
-#pragma unroll
-        for (int kd = 0; kd < 3; ++kd) {
+        // four independent chains of packed FMAs: channel pairs (0,1) (2,3) (4,5) (6,7) as they sit in the 128-bit LDS
+        // reads (written with vector types: left to itself the vectoriser pairs channels across registers and spends
+        // three moves per packed FMA)
+        f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f}, acc45 = {0.f, 0.f}, acc67 = {0.f, 0.f};
+#pragma unroll 1
+        for (int kd = 0; kd < 3; ++kd) {  // not unrolled: 36 LDS reads in flight per pass is all the register file takes
             const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;
-#pragma unroll
+#pragma unroll 1
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float* sp = slab + ((wave + kh) * COLS + lane + kw) * PSTR;
-                    const float4 a = *reinterpret_cast<const float4*>(sp), c = *reinterpret_cast<const float4*>(sp + 4);
-                    const float4 w0 = *reinterpret_cast<const float4*>(wts + ((kd * 3 + kh) * 3 + kw) * 8);
-                    const float4 w1 = *reinterpret_cast<const float4*>(wts + ((kd * 3 + kh) * 3 + kw) * 8 + 4);
-                    acc0 = fmaf(a.x, w0.x, acc0); acc1 = fmaf(a.y, w0.y, acc1); acc2 = fmaf(a.z, w0.z, acc2); acc3 = fmaf(a.w, w0.w, acc3);
-                    acc0 = fmaf(c.x, w1.x, acc0); acc1 = fmaf(c.y, w1.y, acc1); acc2 = fmaf(c.z, w1.z, acc2); acc3 = fmaf(c.w, w1.w, acc3);
+                    const f32x4* sp = reinterpret_cast<const f32x4*>(slab + ((wave + kh) * COLS + lane + kw) * PSTR);
+                    const f32x4* wp = reinterpret_cast<const f32x4*>(wts + ((kd * 3 + kh) * 3 + kw) * 8);
+                    const f32x4 a = sp[0], c = sp[1], w0 = wp[0], w1 = wp[1];
+                    acc01 = __builtin_elementwise_fma(a.xy, w0.xy, acc01);
+                    acc23 = __builtin_elementwise_fma(a.zw, w0.zw, acc23);
+                    acc45 = __builtin_elementwise_fma(c.xy, w1.xy, acc45);
+                    acc67 = __builtin_elementwise_fma(c.zw, w1.zw, acc67);
                 }
         }
-        const float acc = (acc0 + acc1) + (acc2 + acc3);
+        const float acc = ((acc01.x + acc01.y) + (acc23.x + acc23.y)) + ((acc45.x + acc45.y) + (acc67.x + acc67.y));
         if (live) {
             const size_t o = (((size_t)b * p.Do + z) * p.ho + orow) * p.wo + ocol;
             float val = fmaf(acc, sc, sh);
@@ -1133,7 +1139,7 @@ static int launch_c8_to_1(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     p.tiles_h = (p.ho + CONV_TH - 1) / CONV_TH;
     p.tiles_w = (p.wo + 63) / 64;
-    const long long nblk = (long long)p.tiles_w * p.tiles_h * ((p.Do + 15) / 16) * p.B;
+    const long long nblk = (long long)p.tiles_w * p.tiles_h * ((p.Do + C8_DZ - 1) / C8_DZ) * p.B;
     if (nblk > 0x7fffffffLL) {
         set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
         return MVD_ERR_INVALID_ARG;
