@@ -425,11 +425,32 @@ __global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
     store_plane(z0 % 3);
     load_plane(z0 + 1);
 
+    // The float4 stores of plane z are issued at the top of step z+1, BEFORE that step's plane prefetch: vmcnt counts
+    // stores too and retires in order, so stores issued after the prefetch (at the end of step z) made the next
+    // `s_waitcnt vmcnt(0)` in front of the ring store wait for their write acknowledgement — ~1 us of idle matrix
+    // pipe per plane with one wave per SIMD.  Issued first, they have a whole step of MFMAs to complete.
+    float4 pend[MT][NT];
+    float* pend_p[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) pend_p[m][n] = nullptr;
+    auto flush_pending = [&]() {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if (pend_p[m][n]) *reinterpret_cast<float4*>(pend_p[m][n]) = pend[m][n];
+    };
+
     for (int z = z0; z < z1; ++z) {
         __syncthreads();  // step z-1 no longer reads slot (z+1)%3
         store_plane((z + 1) % 3);
         __syncthreads();
-        if (z + 1 < z1) load_plane(z + 2);  // lands during this step's MFMAs
+        flush_pending();     // plane z-1's results
+        load_plane(z + 2);   // lands during this step's MFMAs (unconditional: behind a branch the prefetch registers
+                             // become a phi and the compiler copies — and therefore waits for — them on the spot;
+                             // the last step fetches one plane nobody stores)
 
         f32x4 acc[MT][NT], acc2[SPLIT ? 1 : MT][SPLIT ? 1 : NT];
 #pragma unroll
@@ -569,8 +590,12 @@ __global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
         }
         if constexpr (SPLIT) acc[0][0] += acc2[0][0];
 
-        // ---- epilogue of plane z (same as conv3d_kernel) ----
+        // ---- epilogue of plane z (same as conv3d_kernel); full float4s are stored at the top of the next step ----
         const int orow = r0 + wave;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) pend_p[m][n] = nullptr;
         if (orow < p.ho) {
             const size_t row_base = (((size_t)b * p.Do + z) * p.ho + orow) * p.wo;
 #pragma unroll
@@ -596,7 +621,8 @@ __global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
                         r[k] = val;
                     }
                     if (cb + 3 < p.Cout) {
-                        *reinterpret_cast<float4*>(p.y + o + cb) = make_float4(r[0], r[1], r[2], r[3]);
+                        pend[m][n] = make_float4(r[0], r[1], r[2], r[3]);
+                        pend_p[m][n] = p.y + o + cb;
                     } else {
                         for (int k = 0; k < 4; ++k)
                             if (cb + k < p.Cout) p.y[o + cb + k] = r[k];
@@ -605,6 +631,7 @@ __global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
             }
         }
     }
+    flush_pending();
 }
 
 
