@@ -47,6 +47,7 @@ class PlanesweepCorrelation(nn.Module):
         super().__init__()
         if warp_only or normalize != "dim":
             raise NotImplementedError("only the configuration robust_mvd uses (TorchCorr, normalize='dim') is built")
+        self._invdepth_cache = {}  # (num, min, max, type, device) -> device tensor: constants of the model, uploaded once
 
     @torch.no_grad()
     def forward(self, feat_key, intrinsics_key, feat_sources, source_to_key_transforms, intrinsics_sources=None,
@@ -59,7 +60,14 @@ class PlanesweepCorrelation(nn.Module):
         if min_depth is not None and max_depth is not None:
             if sampling_invdepths is not None or num_sampling_points is None or sampling_type is None:
                 raise ValueError("give either (num_sampling_points, min_depth, max_depth) or sampling_invdepths")
-            sampling_invdepths = compute_sampling_invdepths(min_depth, max_depth, num_sampling_points, sampling_type)
+            scalars = all(isinstance(v, (float, int, np.floating)) for v in (min_depth, max_depth))
+            ckey = (num_sampling_points, float(min_depth), float(max_depth), sampling_type, str(feat_key.device)) if scalars else None
+            if ckey is not None and ckey in self._invdepth_cache:
+                sampling_invdepths = self._invdepth_cache[ckey]  # no host-to-device copy: forward can be graph-captured
+            else:
+                sampling_invdepths = compute_sampling_invdepths(min_depth, max_depth, num_sampling_points, sampling_type)
+                if ckey is not None:
+                    sampling_invdepths = self._invdepth_cache[ckey] = sampling_invdepths.to(feat_key.device)
         elif num_sampling_points is not None or min_depth is not None or max_depth is not None or sampling_invdepths is None:
             raise ValueError("give either (num_sampling_points, min_depth, max_depth) or sampling_invdepths")
         inv = sampling_invdepths.to(feat_key.device)
