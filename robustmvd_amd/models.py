@@ -92,12 +92,14 @@ class RobustMVD(nn.Module):
         device = get_torch_model_device(self)
         _require_multiple(images, 64, "robust_mvd")
         ht, wd = images[0].shape[-2:]
-        images = [im / 255.0 - 0.4 for im in images]
         scale = np.array([[wd] * 3, [ht] * 3, [1.0] * 3], dtype=np.float32)  # relative intrinsics, :118-120
         intrinsics = [k / scale for k in intrinsics]
         images, poses, intrinsics = to_torch((images, poses, intrinsics), device=device)
         keyview_idx = to_torch(keyview_idx)  # stays on the host: only used to order the views
-        images = [im.float() for im in images]
+        # im / 255 - 0.4 (robust_mvd.py:113-116) on the device: the raw images are uploaded, the arithmetic is the
+        # reference's float32 operations one by one (true division by a tensor, not torch's scalar-reciprocal shortcut)
+        c255 = torch.full((1,), 255.0, dtype=torch.float32, device=device)
+        images = [im.float() / c255 - 0.4 for im in images]
         poses = [p.float() for p in poses]
         intrinsics = [k.float() for k in intrinsics]
         return {"images": images, "keyview_idx": keyview_idx, "poses": poses, "intrinsics": intrinsics}
@@ -191,10 +193,13 @@ class MVSNet(nn.Module):
         _require_multiple(images, 32, "mvsnet")
         # images are 0..255: /255 (NormalizeImagesToMinMax(0,1) is a plain rescale, transforms.py:283-288),
         # then ImageNet shift/scale (mvsnet.py:181-183)
-        mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(-1, 1, 1)
-        std = np.array([0.229, 0.224, 0.225], np.float32).reshape(-1, 1, 1)
-        images = [((im / 255.0 - mean) / std).astype(np.float32) for im in images]
         images, masks = to_torch((images, masks), device=device)
+        # (im / 255 - mean) / std on the device, the reference's float32 operations one by one (true divisions by
+        # tensors: torch's division by a python scalar multiplies by the reciprocal, which is not the same rounding)
+        mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32, device=device).view(-1, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32, device=device).view(-1, 1, 1)
+        c255 = torch.full((1,), 255.0, dtype=torch.float32, device=device)
+        images = [(im.float() / c255 - mean) / std for im in images]
         # stay on the host: keyview_idx only orders the views, depth_range only seeds torch.linspace, and the 4x4
         # calibration products are cheaper there than as a dozen tiny launches (forward accepts either placement)
         keyview_idx, depth_range, intrinsics, poses = to_torch((keyview_idx, depth_range, intrinsics, poses))

@@ -225,6 +225,26 @@ def test_robustmvd_two_sources_golden(dev):
     np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=2e-3, rtol=2e-3)
 
 
+def test_input_adapters_normalise_on_device_like_numpy(dev):
+    """the adapters upload raw images and normalise on the GPU: bit-identical to the reference's numpy arithmetic
+    (rmvd/models/mvsnet.py:181-183, robust_mvd.py:113-116)"""
+    import robustmvd_amd as R
+    rng = np.random.default_rng(5)
+    images = [rng.uniform(0, 255, (1, 3, 64, 128)).astype(np.float32) for _ in range(2)]
+    K = gc.synthetic_intrinsics(64, 128)[None]
+    poses = [np.eye(4, dtype=np.float32)[None]] * 2
+    mvs = R.MVSNet(num_sampling_steps=8).to(dev)
+    got = mvs.input_adapter(images=images, keyview_idx=np.array([0]), poses=poses, intrinsics=[K, K], depth_range=(np.array([0.5], np.float32), np.array([10.0], np.float32)))
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(-1, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(-1, 1, 1)
+    for im, g_ in zip(images, got["images"]):
+        assert g_.is_cuda and np.array_equal(g_.cpu().numpy(), ((im / 255.0 - mean) / std).astype(np.float32))
+    rm = R.RobustMVD().to(dev)
+    got = rm.input_adapter(images=images, keyview_idx=np.array([0]), poses=poses, intrinsics=[K, K])
+    for im, g_ in zip(images, got["images"]):
+        assert np.array_equal(g_.cpu().numpy(), (im / 255.0 - 0.4).astype(np.float32))
+
+
 def test_mvsnet_end_to_end_golden(dev):
     import robustmvd_amd as R
     g = load_golden("g8_mvsnet")
