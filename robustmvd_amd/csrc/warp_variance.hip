@@ -144,7 +144,7 @@ __device__ __forceinline__ void gather_blend_4planes(float4 (&s1)[4], float4 (&s
 //     with a plane-major grid every XCD streamed all V source images per plane and the gathers were
 //     served by the Infinity Cache (measured 2.8 ms at the headline shape, profiles/r01_*).
 // Placement only affects speed; results do not depend on it.
-template <int LPP, bool WARP_ONLY, int DPB, int MINW, int REUSE = 0>
+template <int LPP, bool WARP_ONLY, int DPB, int MINW, int REUSE = 0, bool EXACT = false>
 __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) {
     constexpr int PPB = 256 / LPP;  // pixels per block
     constexpr int C = LPP * 4;
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
         // Z == 0 clamps to -1), split into cell and fraction
         auto locate = [&](float depth, float& fwx, float& fwy, unsigned& pixoff) {
             float ix, iy;
-            if (p.exact_grid) {
+            if constexpr (EXACT) {  // a template parameter: as a run-time branch its operands stay live through the loop (16+ VGPRs)
                 // the reference's own chain, one rounding per step: R @ (x*d, y*d, d) + T (utils.py:246-250), perspective
                 // divide, /((W-1)/2) - 1 (:256-257), grid_sample's ((g+1)*W-1)/2
                 const float gx = fx * depth, gy = fy * depth;
@@ -897,7 +897,7 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
     const int lpp = C / 4;
     int dpb, minw, reuse;
     warp_cfg(dpb, minw, reuse);
-    if (lpp != 8) { dpb = 4; minw = 3; reuse = 0; }  // other channel counts: the plain variant
+    if (lpp != 8 || p.exact_grid) { dpb = 4; minw = 3; reuse = 0; }  // other channel counts, exact grids: the plain variant
     const int ppb = 256 / lpp;
     p.tiles_x = (p.w + ppb - 1) / ppb;
     const long long tiles = (long long)p.tiles_x * p.h;
@@ -912,7 +912,15 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
 #define MVD_LAUNCH(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW>), grid, dim3(256), 0, st, p)
 #define MVD_LAUNCH_R(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, 1>), grid, dim3(256), 0, st, p)
 #define MVD_LAUNCH_U(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, 2>), grid, dim3(256), 0, st, p)
-    if (lpp == 8) {
+    if (p.exact_grid) {
+        switch (lpp) {
+            case 1: hipLaunchKernelGGL((warp_variance_kernel<1, WARP_ONLY, 4, 3, 0, true>), grid, dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((warp_variance_kernel<2, WARP_ONLY, 4, 3, 0, true>), grid, dim3(256), 0, st, p); break;
+            case 4: hipLaunchKernelGGL((warp_variance_kernel<4, WARP_ONLY, 4, 3, 0, true>), grid, dim3(256), 0, st, p); break;
+            case 8: hipLaunchKernelGGL((warp_variance_kernel<8, WARP_ONLY, 4, 3, 0, true>), grid, dim3(256), 0, st, p); break;
+            case 16: hipLaunchKernelGGL((warp_variance_kernel<16, WARP_ONLY, 4, 3, 0, true>), grid, dim3(256), 0, st, p); break;
+        }
+    } else if (lpp == 8) {
         switch (reuse * 1000 + dpb * 10 + minw) {
             case 18: MVD_LAUNCH(8, 1, 8); break;
             case 24: MVD_LAUNCH(8, 2, 4); break;
