@@ -132,6 +132,58 @@ __device__ __forceinline__ void gather_blend_4planes(float4 (&s1)[4], float4 (&s
     }
 }
 
+// The same for four waves per SIMD (128 VGPRs): the bilinear weights stay in the locating lane until a plane's
+// arithmetic needs them (4 DPP broadcasts right there instead of 16 registers held through the gathers), and at most
+// three cells are in flight — when all four planes re-gather, plane 3's loads are issued after plane 0's arithmetic
+// into the registers it frees.
+template <int MASK, int I>
+__device__ __forceinline__ void blend_plane_late(float4 (&s1)[4], float4 (&s2)[4], float m00, float m10, float m01, float m11,
+                                                 const u32x4 (&f)[4]) {
+    float w[4];
+    w[0] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m00), I * 0x55, 0xf, 0xf, true));  // quad_perm:[I,I,I,I]
+    w[1] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m10), I * 0x55, 0xf, 0xf, true));
+    w[2] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m01), I * 0x55, 0xf, 0xf, true));
+    w[3] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m11), I * 0x55, 0xf, 0xf, true));
+    accumulate_cell(s1[I], s2[I], w, f);
+}
+
+__device__ __forceinline__ void gather_cell(u32x4 (&f)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned o, unsigned rowb, unsigned pix) {
+    f[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+    f[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + pix, 0, 0);
+    f[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + rowb, 0, 0);
+    f[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + rowb + pix, 0, 0);
+}
+
+template <int MASK>
+__device__ __forceinline__ void gather_blend_4planes_late(float4 (&s1)[4], float4 (&s2)[4], float m00, float m10, float m01,
+                                                          float m11, const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc,
+                                                          unsigned rowb, unsigned pix) {
+    constexpr bool G1 = MASK & 1, G2 = (MASK >> 1) & 1, G3 = (MASK >> 2) & 1;
+    u32x4 a[4], b[4], c[4];  // three register sets
+    gather_cell(a, rsrc, off[0], rowb, pix);
+    if constexpr (MASK == 7) {
+        gather_cell(b, rsrc, off[1], rowb, pix);
+        gather_cell(c, rsrc, off[2], rowb, pix);
+        blend_plane_late<MASK, 0>(s1, s2, m00, m10, m01, m11, a);
+        gather_cell(a, rsrc, off[3], rowb, pix);  // into the set plane 0 just released
+        blend_plane_late<MASK, 1>(s1, s2, m00, m10, m01, m11, b);
+        blend_plane_late<MASK, 2>(s1, s2, m00, m10, m01, m11, c);
+        blend_plane_late<MASK, 3>(s1, s2, m00, m10, m01, m11, a);
+    } else {
+        // at most two of planes 1..3 re-gather: sets b and c take them in order
+        if constexpr (G1) gather_cell(b, rsrc, off[1], rowb, pix);
+        if constexpr (G2) gather_cell(G1 ? c : b, rsrc, off[2], rowb, pix);
+        if constexpr (G3) gather_cell((G1 || G2) ? c : b, rsrc, off[3], rowb, pix);
+        blend_plane_late<MASK, 0>(s1, s2, m00, m10, m01, m11, a);
+        const u32x4 (&p1)[4] = G1 ? b : a;
+        blend_plane_late<MASK, 1>(s1, s2, m00, m10, m01, m11, p1);
+        const u32x4 (&p2)[4] = G2 ? (G1 ? c : b) : p1;
+        blend_plane_late<MASK, 2>(s1, s2, m00, m10, m01, m11, p2);
+        const u32x4 (&p3)[4] = G3 ? ((G1 || G2) ? c : b) : p2;
+        blend_plane_late<MASK, 3>(s1, s2, m00, m10, m01, m11, p3);
+    }
+}
+
 // Work decomposition (the part that decides where the tap gathers are served from):
 //   * a workgroup owns one row segment of PPB key pixels and DPB consecutive depth planes; for each view
 //     it computes the DPB sample positions, issues all 4*DPB gathers back to back (buffer loads: SGPR
@@ -273,6 +325,28 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
             locate(mydep, mwx, mwy, mpo);
             const float mux = 1.0f - mwx, muy = 1.0f - mwy;
             const float m00 = mux * muy, m10 = mwx * muy, m01 = mux * mwy, m11 = mwx * mwy;
+            if constexpr (REUSE == 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) off[i] = 0;
+                off[0] = org + (unsigned)__builtin_amdgcn_mov_dpp((int)mpo, 0 * 0x55, 0xf, 0xf, true);
+                off[1] = org + (unsigned)__builtin_amdgcn_mov_dpp((int)mpo, 1 * 0x55, 0xf, 0xf, true);
+                off[2] = org + (unsigned)__builtin_amdgcn_mov_dpp((int)mpo, 2 * 0x55, 0xf, 0xf, true);
+                off[3] = org + (unsigned)__builtin_amdgcn_mov_dpp((int)mpo, 3 * 0x55, 0xf, 0xf, true);
+                const unsigned mask = (__builtin_amdgcn_ballot_w64(off[1] != off[0]) != 0 ? 1u : 0u) |
+                                      (__builtin_amdgcn_ballot_w64(off[2] != off[1]) != 0 ? 2u : 0u) |
+                                      (__builtin_amdgcn_ballot_w64(off[3] != off[2]) != 0 ? 4u : 0u);
+                switch (mask) {
+                    case 0: gather_blend_4planes_late<0>(s1, s2, m00, m10, m01, m11, off, rsrc, rowb, PIX); break;
+                    case 1: gather_blend_4planes_late<1>(s1, s2, m00, m10, m01, m11, off, rsrc, rowb, PIX); break;
+                    case 2: gather_blend_4planes_late<2>(s1, s2, m00, m10, m01, m11, off, rsrc, rowb, PIX); break;
+                    case 3: gather_blend_4planes_late<3>(s1, s2, m00, m10, m01, m11, off, rsrc, rowb, PIX); break;
+                    case 4: gather_blend_4planes_late<4>(s1, s2, m00, m10, m01, m11, off, rsrc, rowb, PIX); break;
+                    case 5: gather_blend_4planes_late<5>(s1, s2, m00, m10, m01, m11, off, rsrc, rowb, PIX); break;
+                    case 6: gather_blend_4planes_late<6>(s1, s2, m00, m10, m01, m11, off, rsrc, rowb, PIX); break;
+                    default: gather_blend_4planes_late<7>(s1, s2, m00, m10, m01, m11, off, rsrc, rowb, PIX); break;
+                }
+                continue;
+            }
 #define MVD_QB(V, I) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(V), (I) * 0x55, 0xf, 0xf, true))
 #define MVD_QUAD_BCAST(I)                                                                                          \
     wt[I][0] = MVD_QB(m00, I); wt[I][1] = MVD_QB(m10, I); wt[I][2] = MVD_QB(m01, I); wt[I][3] = MVD_QB(m11, I);     \
@@ -869,6 +943,7 @@ static void warp_cfg(int& dpb, int& minw, int& reuse) {
         if (e[0] >= '0' && e[0] <= '9') { sscanf(e, "%d,%d", &dpb, &minw); reuse = 0; }
         if (e[0] == 'r') { sscanf(e, "r%d,%d", &dpb, &minw); reuse = 1; }
         if (e[0] == 'u') { sscanf(e, "u%d,%d", &dpb, &minw); reuse = 2; }
+        if (e[0] == 'v') { sscanf(e, "v%d,%d", &dpb, &minw); reuse = 4; }
     }
 }
 
@@ -912,6 +987,7 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
 #define MVD_LAUNCH(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW>), grid, dim3(256), 0, st, p)
 #define MVD_LAUNCH_R(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, 1>), grid, dim3(256), 0, st, p)
 #define MVD_LAUNCH_U(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, 2>), grid, dim3(256), 0, st, p)
+#define MVD_LAUNCH_V(L, DPB, MW) hipLaunchKernelGGL((warp_variance_kernel<L, WARP_ONLY, DPB, MW, 4>), grid, dim3(256), 0, st, p)
     if (p.exact_grid) {
         switch (lpp) {
             case 1: hipLaunchKernelGGL((warp_variance_kernel<1, WARP_ONLY, 4, 3, 0, true>), grid, dim3(256), 0, st, p); break;
@@ -939,6 +1015,9 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
             case 2042: MVD_LAUNCH_U(8, 4, 2); break;
             case 2043: MVD_LAUNCH_U(8, 4, 3); break;
             case 2044: MVD_LAUNCH_U(8, 4, 4); break;
+            case 4042: MVD_LAUNCH_V(8, 4, 2); break;
+            case 4043: MVD_LAUNCH_V(8, 4, 3); break;
+            case 4044: MVD_LAUNCH_V(8, 4, 4); break;
             case 83: MVD_LAUNCH(8, 8, 3); break;
             default:
                 set_error("warp_variance: MVD_K3_CFG=%d,%d is not a compiled variant", dpb, minw);
@@ -955,6 +1034,7 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
 #undef MVD_LAUNCH
 #undef MVD_LAUNCH_R
 #undef MVD_LAUNCH_U
+#undef MVD_LAUNCH_V
     timing_end(st);
     return launch_status("warp_variance");
 }
