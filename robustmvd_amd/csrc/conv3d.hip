@@ -671,6 +671,189 @@ static int launch_march(const ConvParams& p0, hipStream_t st) {
     return launch_status("conv3d_march");
 }
 
+// conv0 (32 -> 8, PAIR mode) with the reduction dimension split over TWO waves per output row: a workgroup is 8 waves —
+// waves 0-3 take input channels 0-15 of rows 0-3, waves 4-7 channels 16-31 — sharing one ring and one copy of the weights
+// in LDS.  conv3d_march_kernel runs this layer with ONE wave per SIMD (ring 78 KB + weights 74 KB fill the LDS), so every
+// barrier, ring store, epilogue and every vector-ALU instruction between MFMAs (which do not overlap with them on
+// gfx950, tools/micro/mfma_mix.hip) idles the matrix pipe: 69 % busy.  Two waves per SIMD fill each other's gaps.  The
+// second half's partial sums (one float4 per lane) go through LDS at the top of the next step, where a barrier exists
+// anyway.  Accumulation order: (channels 0-15 over all taps) + (channels 16-31 over all taps).
+template <int DZ>
+__global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
+    constexpr int CIN = 32, TW = 16, SX = 2, ROWS = CONV_TH + 2, COLS = 2 * TW + 2, NWT = 4;
+    constexpr int PSTR = CIN, SLAB = ROWS * COLS * PSTR, C4 = CIN / 4, NKG = 2;  // k-groups of 16 channels: one per wave half
+    constexpr int NEL = ROWS * COLS * C4, NPF = (NEL + 511) / 512;
+    constexpr int WFLOATS = 36 * NKG * 64 * 4;
+    constexpr int DUMMY = 3 * SLAB / 4;  // float4 index of the dummy slot behind the ring
+    extern __shared__ __attribute__((aligned(16))) float ring[];  // [3][ROWS][COLS][PSTR] | dummy float4 | weights | partials
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int row = wave & 3, kh_ = wave >> 2;  // output row of the tile, channel half
+    const int vox = lane & 15, q = lane >> 4;
+
+    int bx = blockIdx.x;
+    const int tw = bx % p.tiles_w; bx /= p.tiles_w;
+    const int th = bx % p.tiles_h; bx /= p.tiles_h;
+    const int nzc = (p.Do + DZ - 1) / DZ;
+    const int zc = bx % nzc;
+    const int b = bx / nzc;
+    const int r0 = th * CONV_TH, c0 = tw * TW;
+    const int z0 = zc * DZ, z1 = min(z0 + DZ, p.Do);
+    const int in_r0 = r0 - 1, in_c0 = 2 * c0 - 1;
+
+    int loff[NPF], goff[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int e = tid + 512 * i;
+        const int rw = e / (COLS * C4), rem = e - rw * (COLS * C4);
+        const int col = rem / C4, c4 = rem - col * C4;
+        const int gr = in_r0 + rw, gc = in_c0 + col;
+        const int pc4 = c4 ^ ((col >> 1) & (C4 - 1));  // XOR swizzle of the 16-B channel chunks by the pixel-pair index
+        loff[i] = e < NEL ? ((rw * COLS + col) * PSTR) / 4 + pc4 : DUMMY;
+        goff[i] = (e < NEL && gr >= 0 && gr < p.hi && gc >= 0 && gc < p.wi) ? (gr * p.wi + gc) * C4 + c4 : -1;
+    }
+    const size_t plane_f4 = (size_t)p.hi * p.wi * C4;
+    const float4* __restrict__ xb = reinterpret_cast<const float4*>(p.x) + (size_t)b * p.Di * plane_f4;
+    float4* __restrict__ ring4 = reinterpret_cast<float4*>(ring);
+    float4 pf[NPF];
+    bool pf_ok = false;
+    auto load_plane = [&](int plane) {
+        const bool ok = plane >= 0 && plane < p.Di;  // block-uniform
+        const float4* __restrict__ xp = xb + (size_t)(ok ? plane : 0) * plane_f4;
+        pf_ok = ok;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) pf[i] = xp[max(goff[i], 0)];
+    };
+    auto store_plane = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i)
+            ring4[loff[i] == DUMMY ? DUMMY : slot * (SLAB / 4) + loff[i]] =
+                (pf_ok && goff[i] >= 0) ? pf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    float* __restrict__ wsrc = ring + 3 * SLAB + 4;
+    {
+        float4* __restrict__ wl4 = ring4 + DUMMY + 1;
+        const float4* __restrict__ wg4 = reinterpret_cast<const float4*>(p.wpk);
+        for (int e = tid; e < WFLOATS / 4; e += 512) wl4[e] = wg4[e];
+    }
+    float4* __restrict__ red4 = ring4 + DUMMY + 1 + WFLOATS / 4;  // [4 rows][64 lanes] partial sums of the second half
+
+    float esc[4], esh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        esc[k] = p.scale[4 * (q & 1) + k];
+        esh[k] = p.shift[4 * (q & 1) + k];
+    }
+    load_plane(z0 - 1);
+    store_plane((z0 + 2) % 3);
+    load_plane(z0);
+    store_plane(z0 % 3);
+    load_plane(z0 + 1);
+
+    // first half: its own partial sums of the previous plane, completed and stored at the top of the next step
+    f32x4 mine = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* mine_p = nullptr;
+    const int orow = r0 + row;
+    const int ocol = 2 * (c0 + vox) + (q >> 1);
+    const bool live = orow < p.ho && ocol < p.wo;
+    auto finish_previous = [&]() {  // between the two barriers of a step (or after the last MFMAs + a barrier)
+        if (kh_ == 0 && mine_p) {
+            const float4 o = red4[row * 64 + lane];
+            float r[4];
+            const float a[4] = {mine[0] + o.x, mine[1] + o.y, mine[2] + o.z, mine[3] + o.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[k] = fmaf(a[k], esc[k], esh[k]);
+                if (p.relu) r[k] = fmaxf(r[k], 0.f);
+            }
+            *reinterpret_cast<float4*>(mine_p) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    };
+
+    for (int z = z0; z < z1; ++z) {
+        __syncthreads();  // step z-1 no longer reads slot (z+1)%3; its second-half partials are in red4
+        store_plane((z + 1) % 3);
+        finish_previous();   // plane z-1: issued before this step's prefetch (vmcnt retires in order)
+        __syncthreads();
+        load_plane(z + 2);   // lands during this step's MFMAs (unconditional, see conv3d_march_kernel)
+
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto read_group = [&](int step, int iw, float (&A)[NWT][4], float (&B)[NWT][4]) {
+            const int kd = step / 3, kh = step - kd * 3;
+            const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;  // plane z + kd - 1
+            const int tap = step * 4 + iw;
+            const float4 ta = *reinterpret_cast<const float4*>(wsrc + ((tap * NKG + kh_) * 64 + lane) * 4);
+            A[iw][0] = ta.x; A[iw][1] = ta.y; A[iw][2] = ta.z; A[iw][3] = ta.w;
+            const float* bp = slab + ((row + kh) * COLS + iw) * PSTR + (vox * SX) * PSTR +
+                              (((kh_ * 4 + q) ^ ((vox + (iw >> 1)) & (C4 - 1)))) * 4;
+            const float4 tb = *reinterpret_cast<const float4*>(bp);
+            B[iw][0] = tb.x; B[iw][1] = tb.y; B[iw][2] = tb.z; B[iw][3] = tb.w;
+        };
+        auto mfma_group = [&](int iw, float (&A)[NWT][4], float (&B)[NWT][4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[iw][j], B[iw][j], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[iw][j], B[iw][j], acc, 0, 0, 0);
+            }
+        };
+        float A0[NWT][4], B0[NWT][4], A1[NWT][4], B1[NWT][4];
+#pragma unroll
+        for (int iw = 0; iw < NWT; ++iw) read_group(0, iw, A0, B0);
+#pragma unroll
+        for (int step = 0; step < 9; step += 2) {
+#pragma unroll
+            for (int iw = 0; iw < NWT; ++iw) {
+                if (step + 1 < 9) read_group(step + 1, iw, A1, B1);
+                mfma_group(iw, A0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (step + 1 < 9) {
+#pragma unroll
+                for (int iw = 0; iw < NWT; ++iw) {
+                    if (step + 2 < 9) read_group(step + 2, iw, A0, B0);
+                    mfma_group(iw, A1, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        acc += acc2;
+        if (kh_ == 1) {
+            red4[row * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+            mine = acc;
+            mine_p = live ? p.y + ((((size_t)b * p.Do + z) * p.ho + orow) * p.wo + ocol) * 8 + 4 * (q & 1) : nullptr;
+        }
+    }
+    __syncthreads();
+    finish_previous();
+}
+
+template <int DZ>
+static int launch_conv0_ksplit(const ConvParams& p0, hipStream_t st) {
+    ConvParams p = p0;
+    constexpr int ROWS = CONV_TH + 2, COLS = 34, SLAB = ROWS * COLS * 32, WFLOATS = 36 * 2 * 64 * 4;
+    constexpr size_t lds = (size_t)(3 * SLAB + 4 + WFLOATS + 4 * 64 * 4) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "conv0 k-split: LDS");
+    p.tiles_h = (p.ho + CONV_TH - 1) / CONV_TH;
+    p.tiles_w = ((p.wo + 1) / 2 + 15) / 16;
+    const long long nblk = (long long)p.tiles_w * p.tiles_h * ((p.Do + DZ - 1) / DZ) * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    if (nblk < march_min_blocks()) {  // too few workgroups to fill 256 CUs: shorter chunks, then the other kernels
+        if constexpr (DZ > 8) return launch_conv0_ksplit<8>(p0, st);
+        return -1;
+    }
+    auto kern = conv0_ksplit_kernel<DZ>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return launch_status("conv3d: LDS attribute");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, st, p);
+    return launch_status("conv0_ksplit");
+}
+
 // ConvTranspose3d (k3 s2 p1 op1) with ALL 8 output parity classes in one workgroup: out[2a+p] along each axis
 // uses kernel index 1 on input a (p = 0) or indices 0 / 2 on inputs a+1 / a (p = 1), so every one of the 27 taps
 // belongs to exactly one class (bit per axis = k != 1) and reads the slab at offset (k == 0).  One slab of
@@ -1212,6 +1395,11 @@ static int dispatch_cout(const ConvParams& p, hipStream_t st) {
     if constexpr (MODE == MVD_CONV3D_STRIDE1) {
         const bool old = getenv("MVD_K4_NOMARCH") != nullptr;  // experiments: the plane-at-a-time kernels
         if (p.Cout == 8) {
+            if constexpr (CIN == 32)
+                if (!old && !p.skip && !getenv("MVD_K4_NOKSPLIT")) {  // conv0: two waves per row, split over the input channels
+                    const int rc = launch_conv0_ksplit<16>(p, st);
+                    if (rc >= 0) return rc;
+                }
             if constexpr (CIN <= 32)
                 if (!old) {
                     const int rc = launch_march<CIN, 1, (CIN >= 32 ? 1 : 2), true>(p, st);
