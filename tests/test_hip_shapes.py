@@ -140,10 +140,12 @@ def test_conv3d_modes_vs_oracle(Cin, Cout, mode, D, h, w, relu, skip, dev):
 
 
 def test_conv0_marching_large_grid_vs_oracle(dev):
-    """enough tiles (>= 1024 workgroups) that the depth-marching PAIR kernel is the one that runs, batch 2"""
+    """Grids with >= 1024 depth-marching workgroups (8-plane chunks), so that the kernels the headline shape runs are the
+    ones under test: conv0's k-split PAIR kernel (odd width, ragged rows, a partial last chunk), the 16 -> 16 marching
+    kernel, and the prob kernel — against the C oracle."""
     from robustmvd_amd import ops
     rng = np.random.default_rng(5)
-    B, Cin, Cout, D, h, w = 2, 32, 8, 40, 64, 96
+    B, Cin, Cout, D, h, w = 1, 32, 8, 180, 62, 71   # 3 x 16 x 23 = 1104 workgroups of 8 planes
     x = rng.standard_normal((B, Cin, D, h, w)).astype(np.float32)
     wgt = (rng.standard_normal((Cout, Cin, 3, 3, 3)) * 0.05).astype(np.float32)
     scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
@@ -152,6 +154,19 @@ def test_conv0_marching_large_grid_vs_oracle(dev):
     packed, _, _ = ops.pack_conv3d_weights(T(wgt, dev), 0)
     y = ops.conv3d_bn_relu(T(x, dev).permute(0, 2, 3, 4, 1).contiguous(), packed, Cin, Cout, T(scale, dev), T(shift, dev), 0)
     np.testing.assert_allclose(y.permute(0, 4, 1, 2, 3).cpu().numpy(), ref, atol=ATOL, rtol=RTOL)
+    del x, ref, y
+    # 16 -> 16 (conv2's form): 2 x 16 x 33 = 1056 workgroups of 8 planes
+    D2, h2, w2 = 264, 64, 100
+    x16 = rng.standard_normal((1, 16, D2, h2, w2)).astype(np.float32)
+    w16 = (rng.standard_normal((16, 16, 3, 3, 3)) * 0.07).astype(np.float32)
+    sc16 = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+    sh16 = (rng.standard_normal(16) * 0.1).astype(np.float32)
+    ref16 = CO.conv3d(x16[0], w16, sc16, sh16)
+    pk16, _, _ = ops.pack_conv3d_weights(T(w16, dev), 0)
+    y16 = ops.conv3d_bn_relu(T(x16, dev).permute(0, 2, 3, 4, 1).contiguous(), pk16, 16, 16, T(sc16, dev), T(sh16, dev), 0)
+    np.testing.assert_allclose(y16[0].permute(3, 0, 1, 2).cpu().numpy(), ref16, atol=ATOL, rtol=RTOL)
+    del x16, ref16, y16
+    B, D, h, w = 2, 40, 64, 96
     # prob layer, same grid
     wp = (rng.standard_normal((1, 8, 3, 3, 3)) * 0.1).astype(np.float32)
     x8 = rng.standard_normal((B, 8, D, h, w)).astype(np.float32)
