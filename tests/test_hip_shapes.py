@@ -110,6 +110,9 @@ CONV_CASES = [  # (Cin, Cout, mode, D, h, w, relu, skip)
     (32, 64, 1, 4, 6, 34, True, False), (64, 32, 2, 2, 3, 9, True, True), (32, 16, 2, 3, 5, 20, True, True),
     (16, 8, 2, 3, 6, 70, True, True), (8, 8, 0, 4, 5, 33, False, False), (16, 8, 0, 4, 5, 33, True, False),
     (32, 8, 2, 2, 5, 33, False, False), (64, 8, 2, 2, 3, 17, True, True), (8, 8, 2, 3, 4, 65, True, False),
+    # widths that select the other tile widths (best_mt): 64-wide generic / pair tiles, 32-wide pair, 16-wide stride-2
+    (16, 16, 0, 3, 5, 64, True, False), (8, 16, 1, 4, 8, 128, True, False), (16, 8, 2, 2, 4, 64, True, True),
+    (16, 8, 2, 2, 4, 32, True, False), (32, 64, 1, 4, 6, 96, True, False), (32, 64, 1, 4, 6, 64, True, False),
 ]
 
 
