@@ -103,23 +103,30 @@ def measured_copy_gbs(dev):
     return 2 * 4 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def cpu_baseline(H, W, V, D, sd):
-    """The CPU oracle port (C/OpenMP hot path + torch-CPU 2-D feature net) on ONE full frame of the workload."""
+def cpu_baseline(H, W, V, D, sd, frames=3):
+    """The CPU oracle port (C/OpenMP hot path + torch-CPU 2-D feature net) on a bounded sample of the workload:
+    `frames` full frames (one forward each, 10-15 s of CPU work in total on the GPU box's host)."""
     from oracle import c_oracle as CO
     from oracle import pipeline as PL
-    s = gc.synthetic_sample(0, H, W, V)
     mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
     std = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
-    images = [((im / 255.0 - mean) / std).astype(np.float32)[None] for im in s["images"]]
-    timings = {}
-    t0 = time.perf_counter()
-    PL.mvsnet_forward(images, [p[None] for p in s["poses"]], [k[None] for k in s["intrinsics"]], 0, (0.5, 10.0), sd, D,
-                      timings=timings)
-    dt = time.perf_counter() - t0
+    total, stages = 0.0, {}
+    for f in range(frames):
+        s = gc.synthetic_sample(f, H, W, V)
+        images = [((im / 255.0 - mean) / std).astype(np.float32)[None] for im in s["images"]]
+        timings = {}
+        t0 = time.perf_counter()
+        PL.mvsnet_forward(images, [p[None] for p in s["poses"]], [k[None] for k in s["intrinsics"]], 0, (0.5, 10.0), sd, D,
+                          timings=timings)
+        total += time.perf_counter() - t0
+        for k, v in timings.items():
+            stages[k] = stages.get(k, 0.0) + v / frames
+    dt = total / frames
     return {"value": 1.0 / dt, "unit": "depth-maps/sec", "cores": CO.num_threads(), "kind": "port",
-            "sample": f"1 full frame {H}x{W} V{V} D{D} (one forward, {dt:.1f} s; oracle/pipeline.py: C/OpenMP warp+variance "
-                      f"{timings['warp_variance']:.1f} s, CostRegNet {timings['cost_reg']:.1f} s, soft-argmin "
-                      f"{timings['regress']:.2f} s, torch-CPU FeatureNet {timings['features']:.1f} s)",
+            "sample": f"{frames} full frames {H}x{W} V{V} D{D} (one forward each, {total:.1f} s in total, {dt:.1f} s per frame; "
+                      f"oracle/pipeline.py: C/OpenMP warp+variance {stages['warp_variance']:.1f} s, CostRegNet "
+                      f"{stages['cost_reg']:.1f} s, soft-argmin {stages['regress']:.2f} s, torch-CPU FeatureNet "
+                      f"{stages['features']:.1f} s)",
             "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()}
 
 

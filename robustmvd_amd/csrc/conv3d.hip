@@ -725,11 +725,19 @@ __global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) pf[i] = xp[max(goff[i], 0)];
     };
+    // tiles whose halo lies inside the image (3 of 4 at the headline shape) store the prefetched plane as it is: the
+    // zeroing selects are vector-ALU work, which on gfx950 stalls the matrix pipe
+    const bool interior = in_r0 >= 0 && in_r0 + ROWS <= p.hi && in_c0 >= 0 && in_c0 + COLS <= p.wi;  // block-uniform
     auto store_plane = [&](int slot) {
+        if (interior && pf_ok) {
 #pragma unroll
-        for (int i = 0; i < NPF; ++i)
-            ring4[loff[i] == DUMMY ? DUMMY : slot * (SLAB / 4) + loff[i]] =
-                (pf_ok && goff[i] >= 0) ? pf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < NPF; ++i) ring4[loff[i] == DUMMY ? DUMMY : slot * (SLAB / 4) + loff[i]] = pf[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPF; ++i)
+                ring4[loff[i] == DUMMY ? DUMMY : slot * (SLAB / 4) + loff[i]] =
+                    (pf_ok && goff[i] >= 0) ? pf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
 
     float* __restrict__ wsrc = ring + 3 * SLAB + 4;
