@@ -1233,12 +1233,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
     // prefetched into registers while the current output plane is computed
     constexpr int CIN = 8, TW = 64, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR;
     constexpr int NEL = ROWS * COLS * 2, NPF = (NEL + 255) / 256, DZ = C8_DZ;
-    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 216 + 4];  // 57 KB + the weights + dummy slot
-    // the 216 weights sit in LDS (broadcast reads): scalar-cache loads inside the tap loop would share lgkmcnt
-    // with the ds_reads and, returning out of order, force a full drain per tap
-    float* __restrict__ wts = ring + 3 * SLAB;
+    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 4];  // 57 KB + dummy slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 216) wts[tid] = p.wpk[tid];
     int bx = blockIdx.x;
     const int tw = bx % p.tiles_w; bx /= p.tiles_w;
     const int th = bx % p.tiles_h; bx /= p.tiles_h;
@@ -1255,7 +1251,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
         const int row = e / (COLS * 2), rem = e - row * (COLS * 2);
         const int col = rem >> 1, c4 = rem & 1;
         const int gr = r0 - 1 + row, gc = c0 - 1 + col;
-        constexpr int DUMMY = (3 * SLAB + 216) / 4;
+        constexpr int DUMMY = (3 * SLAB) / 4;
         loff[i] = e < NEL ? ((row * COLS + col) * PSTR) / 4 + c4 : DUMMY;  // float4 units (see conv3d_march_kernel)
         goff[i] = (e < NEL && gr >= 0 && gr < p.hi && gc >= 0 && gc < p.wi) ? (gr * p.wi + gc) * 2 + c4 : -1;
     }
@@ -1272,7 +1268,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
         for (int i = 0; i < NPF; ++i) pf[i] = xp[max(goff[i], 0)];  // raw: zeroing happens at store time, so that
     };                                                              // nothing touches pf while the loads are in flight
     auto store_plane = [&](int slot) {
-        constexpr int DUMMY = (3 * SLAB + 216) / 4;
+        constexpr int DUMMY = (3 * SLAB) / 4;
 #pragma unroll
         for (int i = 0; i < NPF; ++i)
             ring4[loff[i] == DUMMY ? DUMMY : slot * (SLAB / 4) + loff[i]] =
@@ -1304,7 +1300,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
                     const f32x4* sp = reinterpret_cast<const f32x4*>(slab + ((wave + kh) * COLS + lane + kw) * PSTR);
-                    const f32x4* wp = reinterpret_cast<const f32x4*>(wts + ((kd * 3 + kh) * 3 + kw) * 8);
+                    // constant address space: the loads are invariant for the compiler, so the (uniform) address goes
+                    // through the scalar cache and the weights arrive as SGPR-pair operands of the packed FMAs.  Every
+                    // (kd, kh) pass issues its 6 LDS reads and 3 scalar loads together and waits once, so sharing lgkmcnt
+                    // costs nothing — and the LDS pipe, which bounds this kernel, carries half the reads.
+                    typedef const __attribute__((address_space(4))) f32x4* cf4;
+                    const cf4 wp = (cf4)(unsigned long long)(p.wpk + ((kd * 3 + kh) * 3 + kw) * 8);
                     const f32x4 a = sp[0], c = sp[1], w0 = wp[0], w1 = wp[1];
                     acc01 = __builtin_elementwise_fma(a.xy, w0.xy, acc01);
                     acc23 = __builtin_elementwise_fma(a.zw, w0.zw, acc23);
