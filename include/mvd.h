@@ -176,6 +176,12 @@ int mvd_softmax_regress_f32(const float* cost, const float* depth_values, int B,
  * disarm.  Nothing is synchronised; the caller reads the events after synchronising the stream. */
 int mvd_arm_kernel_timing(void* start_event, void* stop_event);
 
+/* Epilogue of the DispNet 2-D convolutions around the Path-A sweep (rmvd/models/blocks/dispnet_encoder.py,
+ * dispnet_costvolume_encoder.py, dispnet_decoder.py: Conv2d / ConvTranspose2d with bias followed by LeakyReLU(0.2)):
+ *   x[n][c][i] = leaky_relu(x[n][c][i] + bias[c], slope), in place, x (N,C,HW) contiguous.
+ * The convolutions themselves stay on the vendor library; this replaces the two elementwise passes after each. */
+int mvd_bias_leaky_relu_f32(float* x, const float* bias, int N, int C, long long HW, float slope, mvd_stream_t stream);
+
 /* layout helpers used at the operator-level boundary (reference tensors are NCHW / NCDHW) */
 int mvd_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);
 int mvd_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);

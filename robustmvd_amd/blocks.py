@@ -264,9 +264,27 @@ class CostRegNet(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # DispNet 2-D CNN around the Path-A sweep (plain torch; MIOpen)
 # ------------------------------------------------------------------------------------------------
+class _ConvLeaky(nn.Sequential):
+    """[0] = Conv2d / ConvTranspose2d with bias, [1] = LeakyReLU(0.2) — the reference's nn.Sequential (same state-dict
+    keys).  Inference on the GPU runs the convolution without bias on the vendor library and applies bias + LeakyReLU
+    in one in-place pass (ops.bias_leaky_relu_) instead of torch's two; same fp32 operations, bit-identical."""
+
+    def forward(self, x):
+        c = self[0]
+        if torch.is_grad_enabled() or not x.is_cuda or c.bias is None:
+            return super().forward(x)
+        if isinstance(c, nn.ConvTranspose2d):
+            y = F.conv_transpose2d(x, c.weight, None, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
+        else:
+            y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        if not y.is_contiguous() or y.shape[0] * y.shape[1] > 65535:
+            return F.leaky_relu(y + c.bias.view(1, -1, 1, 1), self[1].negative_slope, inplace=True)
+        return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope)
+
+
 def conv(cin, cout, kernel_size=3, stride=1):
-    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=True),
-                         nn.LeakyReLU(0.2, inplace=True))
+    return _ConvLeaky(nn.Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=True),
+                      nn.LeakyReLU(0.2, inplace=True))
 
 
 class ReLUAndSigmoid(nn.Module):
@@ -329,13 +347,13 @@ def _pred_block(cin):
 
 
 def _deconv(cin, cout):
-    return nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1, bias=True),
-                         nn.LeakyReLU(0.2, inplace=True))
+    return _ConvLeaky(nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1, bias=True),
+                      nn.LeakyReLU(0.2, inplace=True))
 
 
 def _iconv(cin, cout):
-    return nn.Sequential(nn.Conv2d(cin + 2, cout, kernel_size=3, stride=1, padding=1, bias=True),
-                         nn.LeakyReLU(0.2, inplace=True))
+    return _ConvLeaky(nn.Conv2d(cin + 2, cout, kernel_size=3, stride=1, padding=1, bias=True),
+                      nn.LeakyReLU(0.2, inplace=True))
 
 
 class DispnetDecoder(nn.Module):

@@ -59,9 +59,45 @@ int transpose_launch(const float* src, float* dst, int N, long long rows, long l
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)nblk), dim3(256), 0, st, src, dst, rows, cols);
     return launch_status("transpose");
 }
+// x[n][c][i] = leaky_relu(x[n][c][i] + bias[c]) in place: the epilogue of the DispNet convolutions around the Path-A
+// sweep (rmvd/models/blocks/dispnet_*.py: Conv2d(bias=True) + LeakyReLU(0.2)), which torch runs as two extra passes
+template <bool VEC>
+__global__ void __launch_bounds__(256) bias_leaky_relu_kernel(float* __restrict__ x, const float* __restrict__ bias, int C,
+                                                              long long HW, float slope) {
+    const long long row = blockIdx.y;  // n * C + c
+    const float b = bias[row % C];
+    float* __restrict__ xr = x + row * HW;
+    if constexpr (VEC) {
+        float4* __restrict__ x4 = reinterpret_cast<float4*>(xr);
+        const long long n4 = HW / 4;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            float4 v = x4[i];
+            v.x += b; v.y += b; v.z += b; v.w += b;
+            v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+            v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+            x4[i] = v;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+            const float v = xr[i] + b;
+            xr[i] = v > 0.f ? v : v * slope;
+        }
+    }
+}
 }  // namespace mvd
 
 extern "C" {
+int mvd_bias_leaky_relu_f32(float* x, const float* bias, int N, int C, long long HW, float slope, mvd_stream_t stream) {
+    MVD_REQUIRE(x && bias && N > 0 && C > 0 && HW > 0, "bias_leaky_relu: bad argument");
+    MVD_REQUIRE((long long)N * C <= 65535, "bias_leaky_relu: N*C = %lld exceeds the grid limit", (long long)N * C);
+    const bool vec = HW % 4 == 0 && ((size_t)x % 16) == 0;
+    const long long per_row = vec ? HW / 4 : HW;
+    const unsigned gx = (unsigned)((per_row + 255) / 256 > 256 ? 256 : (per_row + 255) / 256);
+    const dim3 grid(gx, (unsigned)((long long)N * C));
+    if (vec) hipLaunchKernelGGL(mvd::bias_leaky_relu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, bias, C, HW, slope);
+    else hipLaunchKernelGGL(mvd::bias_leaky_relu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, bias, C, HW, slope);
+    return mvd::launch_status("bias_leaky_relu");
+}
 int mvd_version(void) { return MVD_VERSION; }
 const char* mvd_last_error(void) { return mvd::g_err; }
 int mvd_arm_kernel_timing(void* start_event, void* stop_event) {

@@ -281,6 +281,20 @@ def softmax_regress(cost, depth_values, with_confidence=True):
 
 
 @torch.no_grad()
+def bias_leaky_relu_(x, bias, slope=0.2):
+    """In place: x (N,C,H,W) contiguous <- leaky_relu(x + bias[c], slope).  Returns x."""
+    lib = L.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() >= 2):
+        raise ValueError("bias_leaky_relu_: x must be a contiguous fp32 device tensor (N,C,...)")
+    N, C = x.shape[0], x.shape[1]
+    b = L.as_f32(bias, "bias", (C,), x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mvd_bias_leaky_relu_f32(L.ptr(x), L.ptr(b), N, C, x.numel() // (N * C), float(slope), L.stream_of(x))
+    L.check(rc, "mvd_bias_leaky_relu_f32")
+    return x
+
+
+@torch.no_grad()
 def to_channels_last_3d(x):
     """(B,C,D,h,w) -> (B,D,h,w,C) through the library's tiled transpose."""
     lib = L.load()

@@ -225,6 +225,21 @@ def test_robustmvd_two_sources_golden(dev):
     np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=2e-3, rtol=2e-3)
 
 
+def test_dispnet_conv_epilogue_is_bit_identical_to_torch(dev):
+    """_ConvLeaky: conv without bias + the fused in-place bias/LeakyReLU pass equals torch's conv(bias) -> LeakyReLU."""
+    from robustmvd_amd import blocks
+    torch.manual_seed(3)
+    for mod, shape in ((blocks.conv(3, 64, kernel_size=7, stride=2), (2, 3, 64, 96)), (blocks.conv(32, 16), (1, 32, 13, 17)),
+                       (blocks._deconv(24, 12), (2, 24, 9, 11)), (blocks._iconv(14, 8), (1, 16, 10, 6))):
+        mod = mod.to(dev).eval()
+        x = torch.randn(*shape, device=dev)
+        with torch.no_grad():
+            got = mod(x)
+        with torch.enable_grad():
+            want = mod(x).detach()   # the plain nn.Sequential path
+        assert torch.equal(got, want)
+
+
 def test_input_adapters_normalise_on_device_like_numpy(dev):
     """the adapters upload raw images and normalise on the GPU: bit-identical to the reference's numpy arithmetic
     (rmvd/models/mvsnet.py:181-183, robust_mvd.py:113-116)"""
