@@ -882,6 +882,166 @@ __global__ void __launch_bounds__(256, 2) warp_variance_wave_kernel(WarpParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Experimental (MVD_K3_CFG=q8): C = 32, channel-last output, folded grid arithmetic, ONE QUAD PER KEY PIXEL with 8
+// channels per lane and 2 planes per workgroup.  The per-(pixel, plane, view) overhead of the direct kernel (position
+// arithmetic, DPP broadcasts, re-gather pattern, addresses) is amortised over twice the FMAs per lane; lanes q and q^2
+// of a quad both locate plane q & 1.  Bit-identical to the direct kernel.
+__device__ __forceinline__ void gather_cell_q8(u32x4 (&f)[4], u32x4 (&g)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned o, unsigned rowb) {
+    constexpr unsigned PIX = 128;
+    f[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+    g[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 16, 0, 0);
+    f[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + PIX, 0, 0);
+    g[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + PIX + 16, 0, 0);
+    f[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + rowb, 0, 0);
+    g[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + rowb + 16, 0, 0);
+    f[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + rowb + PIX, 0, 0);
+    g[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + rowb + PIX + 16, 0, 0);
+}
+
+template <bool ANY1>
+__device__ __forceinline__ void step_q8(float4 (&s1)[2][2], float4 (&s2)[2][2], const float (&w0)[4], const float (&w1)[4],
+                                        unsigned o0, unsigned o1, __amdgpu_buffer_rsrc_t rsrc, unsigned rowb) {
+    u32x4 f0[4], g0[4], f1[4], g1[4];
+    gather_cell_q8(f0, g0, rsrc, o0, rowb);
+    if constexpr (ANY1) gather_cell_q8(f1, g1, rsrc, o1, rowb);
+    accumulate_cell(s1[0][0], s2[0][0], w0, f0);
+    accumulate_cell(s1[0][1], s2[0][1], w0, g0);
+    accumulate_cell(s1[1][0], s2[1][0], w1, ANY1 ? f1 : f0);
+    accumulate_cell(s1[1][1], s2[1][1], w1, ANY1 ? g1 : g0);
+}
+
+template <int MINW, int CPB>
+__global__ void __launch_bounds__(256, MINW) warp_variance_q8_kernel(WarpParams p) {
+    constexpr unsigned PIX = 128;
+    const int tid = threadIdx.x;
+    const int q = tid & 3;    // channels 8q .. 8q+7; locates plane d0 + (q & 1)
+    const int px = tid >> 2;  // 0..63: 32 columns x 2 rows
+    const int h = p.h, w = p.w, D = p.D;
+
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int dchunks = (D + 2 * CPB - 1) / (2 * CPB);  // CPB chunks of 2 planes per workgroup: one index decode and key fetch for all
+    const int dc = j % dchunks; j /= dchunks;
+    const int tile_in = j % p.tiles_per_xcd;
+    const int b = j / p.tiles_per_xcd;
+    const int tile = xcd * p.tiles_per_xcd + tile_in;
+    if (tile >= p.tiles_x * p.tiles_y) return;  // block-uniform
+    const int ty = tile / p.tiles_x;
+    const int x = (tile - ty * p.tiles_x) * 32 + (px & 31);
+    const int y = ty * 2 + (px >> 5);
+    const bool active = x < w && y < h;
+    const int xc = min(x, w - 1), yc = min(y, h - 1);
+
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float fx = (float)xc, fy = (float)yc;
+    const float xhi = (float)w, yhi = (float)h;
+    const int W2 = w + 3;
+    const float W2f = (float)W2;
+    const unsigned rowb = (unsigned)W2 * PIX;
+    const unsigned img_bytes = (unsigned)(h + 3) * rowb;
+    const unsigned org = rowb + PIX + (unsigned)q * 32;
+
+    float4 k0, k1;
+    {
+        const float4* kp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.key) + (size_t)b * img_bytes + org +
+                                                           (unsigned)yc * rowb + (unsigned)xc * PIX);
+        k0 = kp[0]; k1 = kp[1];
+    }
+    const float inv_nv = 1.0f / (float)(p.V + 1);  // mvsnet.py:135, V there counts the key view
+#pragma unroll 1
+    for (int cc = 0; cc < CPB; ++cc) {
+    const int d0 = (dc * CPB + cc) * 2;
+    if (d0 >= D) break;  // block-uniform
+    float4 s1[2][2], s2[2][2];  // [plane][channel half]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        s1[i][0] = k0; s1[i][1] = k1;
+        s2[i][0] = make_float4(k0.x * k0.x, k0.y * k0.y, k0.z * k0.z, k0.w * k0.w);
+        s2[i][1] = make_float4(k1.x * k1.x, k1.y * k1.y, k1.z * k1.z, k1.w * k1.w);
+    }
+    const float mydep = p.depth[(size_t)b * D + min(d0 + (q & 1), D - 1)];
+
+    float Mn[12];
+    const char* srcn;
+    auto fetch_view = [&](int v) {
+        const float* __restrict__ Mv = p.M + ((size_t)v * p.B + b) * 12;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Mn[k] = Mv[k];
+        srcn = reinterpret_cast<const char*>(p.src.p[v]);
+    };
+    fetch_view(0);
+    for (int v = 0; v < p.V; ++v) {
+        float M[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) M[k] = Mn[k];
+        const char* srcv = srcn;
+        fetch_view(min(v + 1, p.V - 1));
+        const float ax = fmaf(M[0], fx, fmaf(M[1], fy, M[2]));
+        const float ay = fmaf(M[4], fx, fmaf(M[5], fy, M[6]));
+        const float az = fmaf(M[8], fx, fmaf(M[9], fy, M[10]));
+        const float X = fmaf(ax, mydep, M[3]), Y = fmaf(ay, mydep, M[7]), Z = fmaf(az, mydep, M[11]);
+        const float rz = __builtin_amdgcn_rcpf(Z);
+        float ix = fmaf(X * rz, sx, -0.5f), iy = fmaf(Y * rz, sy, -0.5f);
+        ix = __builtin_amdgcn_fmed3f(ix, -1.0f, xhi);
+        iy = __builtin_amdgcn_fmed3f(iy, -1.0f, yhi);
+        const float xf = floorf(ix), yf = floorf(iy);
+        const float mwx = ix - xf, mwy = iy - yf;
+        const unsigned mpo = (unsigned)(int)fmaf(yf, W2f, xf) * PIX;
+        const float mux = 1.0f - mwx, muy = 1.0f - mwy;
+        const float m00 = mux * muy, m10 = mwx * muy, m01 = mux * mwy, m11 = mwx * mwy;
+        float wt[2][4];
+        unsigned off[2];
+#define MVD_QB(V, I) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(V), (I) * 0x55, 0xf, 0xf, true))
+#define MVD_QUAD_BCAST(I)                                                                                          \
+    wt[I][0] = MVD_QB(m00, I); wt[I][1] = MVD_QB(m10, I); wt[I][2] = MVD_QB(m01, I); wt[I][3] = MVD_QB(m11, I);     \
+    off[I] = org + (unsigned)__builtin_amdgcn_mov_dpp((int)mpo, (I) * 0x55, 0xf, 0xf, true);  /* quad_perm:[I,I,I,I] */
+        MVD_QUAD_BCAST(0) MVD_QUAD_BCAST(1)
+#undef MVD_QUAD_BCAST
+#undef MVD_QB
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(srcv + (size_t)b * img_bytes), 0, (int)img_bytes, 0x00020000);
+        if (__builtin_amdgcn_ballot_w64(off[1] != off[0]) != 0) step_q8<true>(s1, s2, wt[0], wt[1], off[0], off[1], rsrc, rowb);
+        else step_q8<false>(s1, s2, wt[0], wt[1], off[0], off[1], rsrc, rowb);
+    }
+
+    if (active) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int d = d0 + i;
+        if (d >= D) break;  // block-uniform
+        float4* op = reinterpret_cast<float4*>(p.out + ((((size_t)b * D + d) * h + y) * w + x) * 32 + q * 8);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const float mx = s1[i][hf].x * inv_nv, my = s1[i][hf].y * inv_nv, mz = s1[i][hf].z * inv_nv, mw = s1[i][hf].w * inv_nv;
+            op[hf] = make_float4(fmaf(s2[i][hf].x, inv_nv, -mx * mx), fmaf(s2[i][hf].y, inv_nv, -my * my),
+                                 fmaf(s2[i][hf].z, inv_nv, -mz * mz), fmaf(s2[i][hf].w, inv_nv, -mw * mw));
+        }
+    }
+    }
+    }
+}
+
+static int launch_warp_q8(const WarpParams& p0, hipStream_t st, int minw) {
+    WarpParams p = p0;
+    p.tiles_x = (p.w + 31) / 32;
+    p.tiles_y = (p.h + 1) / 2;
+    const long long tiles = (long long)p.tiles_x * p.tiles_y;
+    p.tiles_per_xcd = (int)((tiles + 7) / 8);
+    // (several 2-plane chunks per workgroup, to amortise the index decode and key fetch, measured 1.5 ms: CPB stays 1)
+    const long long nblk = 8LL * p.tiles_per_xcd * ((p.D + 1) / 2) * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("warp_variance: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    timing_begin(st);
+    const dim3 grid((unsigned)nblk);
+    if (minw == 3) hipLaunchKernelGGL((warp_variance_q8_kernel<3, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((warp_variance_q8_kernel<4, 1>), grid, dim3(256), 0, st, p);
+    timing_end(st);
+    return launch_status("warp_variance_q8");
+}
+
 static int launch_warp_wave(const WarpParams& p0, hipStream_t st, int nd) {
     WarpParams p = p0;
     p.tiles_x = (p.w + 15) / 16;  // groups of 4 wave tiles (16 x 2 pixels)
@@ -1103,6 +1263,10 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
                 int nd = 4;
                 sscanf(e, "lds,%d", &nd);
                 return launch_warp_lds(p, st, nd);
+            } else if (e[0] == 'q') {
+                int mw = 4;
+                sscanf(e, "q8,%d", &mw);
+                return launch_warp_q8(p, st, mw);
             } else if (e[0] == 'w') {
                 int nd = 8;
                 sscanf(e, "wave,%d", &nd);

@@ -333,7 +333,7 @@ def test_full_size_regulariser_and_regression_properties(dev):
     np.testing.assert_allclose(cc[0].cpu().numpy(), ref, atol=2e-4, rtol=1e-3)
 
 
-@pytest.mark.parametrize("cfg", ["lds,4", "lds,8", "wave,4", "wave,8", "4,3", "8,2", "r4,3", "u4,2", "v4,3", "v4,4"])
+@pytest.mark.parametrize("cfg", ["lds,4", "lds,8", "wave,4", "wave,8", "4,3", "8,2", "r4,3", "u4,2", "v4,3", "v4,4", "q8,4", "q8,3"])
 def test_warp_variance_experimental_variants_match_default(cfg, dev, monkeypatch):
     """the compiled-in experimental forms of K3 (LDS-staged footprints, other plane/occupancy splits) give the
     same volume as the default kernel bit for bit, including tiles whose footprint falls back to direct gathers"""
