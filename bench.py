@@ -216,14 +216,13 @@ def main():
     if os.environ.get("MVD_BENCH_PIPELINED", "1") == "1":
         import torch.distributed as dist
         from robustmvd_amd.sharding import timed_region
+        import robustmvd_amd as R
         nfl = 2
-        streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
+        pipe = R.FramePipeline(model, depth=nfl)
 
         def run_pipelined(n):
-            with torch.no_grad():
-                for i in range(n):
-                    with torch.cuda.stream(streams[i % nfl]):
-                        model(**samples[i % len(samples)])
+            for i in range(n):
+                pipe.submit(**samples[i % len(samples)])
 
         run_pipelined(args.warmup + 2)
         torch.cuda.synchronize(dev)

@@ -13,3 +13,4 @@ from . import models  # noqa: F401  (registers robust_mvd, robust_mvd_5M, mvsnet
 from .blocks import (PlanesweepCorrelation, LearnedFusion, CostRegNet, homo_warp, depth_regression,  # noqa: F401
                      compute_sampling_invdepths)
 from .models import RobustMVD, MVSNet  # noqa: F401
+from .serving import FramePipeline  # noqa: F401

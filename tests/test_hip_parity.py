@@ -240,6 +240,38 @@ def test_dispnet_conv_epilogue_is_bit_identical_to_torch(dev):
         assert torch.equal(got, want)
 
 
+def test_frame_pipeline_matches_sequential_forwards(dev):
+    """FramePipeline: frames in flight on separate streams give exactly the sequential results, in submission order."""
+    import robustmvd_amd as R
+    from robustmvd_amd.registry import add_batch_dim
+    g = load_golden("g8_mvsnet")
+    H, W, D, V = [int(v) for v in g["shape"]]
+    model = R.MVSNet(num_sampling_steps=D).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    full = model.state_dict()
+    for k, v in gc.fill_state_dict(shapes, int(g["weight_seed"])).items():
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    model = model.to(dev)
+
+    def sample(seed):
+        s = gc.synthetic_sample(seed, H, W, V)
+        im, key, po, intr, dr = add_batch_dim(s["images"], 0, s["poses"], s["intrinsics"], (np.float32(0.5), np.float32(10.0)))
+        return model.input_adapter(images=im, keyview_idx=key, poses=po, intrinsics=intr, depth_range=dr)
+
+    samples = [sample(int(g["sample_seed"]) + i) for i in range(5)]
+    with torch.no_grad():
+        want = [model(**s)[0]["depth"].clone() for s in samples]
+    pipe = R.FramePipeline(model, depth=3)
+    tickets = [pipe.submit(**s) for s in samples]
+    got = [t.result()[0]["depth"] for t in tickets]
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(got[0].cpu().numpy(), g["depth"], rtol=1e-3)
+    with pytest.raises(ValueError):
+        R.FramePipeline(model, depth=0)
+
+
 def test_input_adapters_normalise_on_device_like_numpy(dev):
     """the adapters upload raw images and normalise on the GPU: bit-identical to the reference's numpy arithmetic
     (rmvd/models/mvsnet.py:181-183, robust_mvd.py:113-116)"""
