@@ -27,7 +27,8 @@ struct Conv2dParams {
     float* y;
     int B, hi, wi, ho, wo, Cout, relu;
     int tiles_w, tiles_h, tiles_per_xcd;
-    long long osb, osr, osc, osch, oorg;  // output strides (floats): batch, row, column, channel; origin offset
+    long long osb, oorg;  // output batch stride and origin offset (floats)
+    int osr, osc, osch;   // row, column and channel strides inside one image (floats; an image holds < 2^31)
 };
 
 template <int CIN>
@@ -141,12 +142,13 @@ __global__ void __launch_bounds__(256) conv2d_kernel(Conv2dParams p) {
         bool ok[NPF];
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
+            // a slab row is one contiguous span of the channel-last input: element `rem` of row `row` sits `rem` float4s
+            // behind the row's first pixel — 32-bit index arithmetic, one 64-bit add per load
             const int e = tid + 256 * i;
             const int row = e / (COLS * C4), rem = e - row * (COLS * C4);
-            const int col = rem / C4, c4 = rem - col * C4;
-            const int gr = in_r0 + row, gc = in_c0 + col;
+            const int gr = in_r0 + row, gc = in_c0 + rem / C4;
             ok[i] = e < NEL && gr >= 0 && gr < p.hi && gc >= 0 && gc < p.wi;
-            pf[i] = xb4[ok[i] ? ((size_t)gr * p.wi + gc) * C4 + c4 : 0];
+            pf[i] = xb4[ok[i] ? (gr * p.wi + in_c0) * C4 + rem : 0];
         }
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(Conv2dParams p) {
         for (int m = 0; m < MT; ++m) {
             const int ocol = c0 + m * 16 + vox;
             if (ocol >= p.wo) continue;
-            float* __restrict__ yp = yb + (size_t)orow * p.osr + (size_t)ocol * p.osc;
+            float* __restrict__ yp = yb + (orow * p.osr + ocol * p.osc);  // 32-bit arithmetic, one 64-bit add
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int cb = n * 16 + q * 4;  // first of this lane's 4 output channels
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(Conv2dParams p) {
                     *reinterpret_cast<float4*>(yp + cb) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) yp[(size_t)(cb + k) * p.osch] = v[k];
+                    for (int k = 0; k < 4; ++k) yp[(cb + k) * p.osch] = v[k];
                 }
             }
         }
@@ -323,6 +325,7 @@ int mvd_conv2d_bn_relu_f32(const float* x, int in_layout, const float* packed_w,
                            int relu, mvd_stream_t stream) {
     MVD_REQUIRE(x && packed_w && scale && shift && y, "conv2d: NULL argument");
     MVD_REQUIRE(B > 0 && hi > 0 && wi > 0, "conv2d: non-positive dimension");
+    MVD_REQUIRE((long long)(hi + 3) * (wi + 3) * 32 < 0x7fffffffLL, "conv2d: one %dx%d image exceeds the 32-bit index range", hi, wi);
     MVD_REQUIRE(mvd::cin2d_ok(Cin) && mvd::cout2d_ok(Cout), "conv2d: Cin=%d/Cout=%d unsupported", Cin, Cout);
     MVD_REQUIRE((Cin == 3) == (in_layout == MVD_LAYOUT_NCHW), "conv2d: a 3-channel input must be NCHW and a wider one NHWC");
     MVD_REQUIRE(in_layout == MVD_LAYOUT_NCHW || in_layout == MVD_LAYOUT_NHWC, "conv2d: in_layout=%d unknown", in_layout);
@@ -333,10 +336,10 @@ int mvd_conv2d_bn_relu_f32(const float* x, int in_layout, const float* packed_w,
     p.wo = (wi - 1) / stride + 1;
     const long long C = Cout;
     switch (out_layout) {
-        case MVD_LAYOUT_NHWC: p.osb = (long long)p.ho * p.wo * C; p.osr = p.wo * C; p.osc = C; p.osch = 1; p.oorg = 0; break;
+        case MVD_LAYOUT_NHWC: p.osb = (long long)p.ho * p.wo * C; p.osr = (int)(p.wo * C); p.osc = (int)C; p.osch = 1; p.oorg = 0; break;
         case MVD_LAYOUT_NHWC_BORDER:  // (B, ho+3, wo+3, C) with the image at (1,1): K3's staging layout
-            p.osb = (long long)(p.ho + 3) * (p.wo + 3) * C; p.osr = (p.wo + 3) * C; p.osc = C; p.osch = 1; p.oorg = p.osr + C; break;
-        case MVD_LAYOUT_NCHW: p.osb = C * p.ho * p.wo; p.osr = p.wo; p.osc = 1; p.osch = (long long)p.ho * p.wo; p.oorg = 0; break;
+            p.osb = (long long)(p.ho + 3) * (p.wo + 3) * C; p.osr = (int)((p.wo + 3) * C); p.osc = (int)C; p.osch = 1; p.oorg = p.osr + C; break;
+        case MVD_LAYOUT_NCHW: p.osb = C * p.ho * p.wo; p.osr = p.wo; p.osc = 1; p.osch = p.ho * p.wo; p.oorg = 0; break;
         default: mvd::set_error("conv2d: out_layout=%d unknown", out_layout); return MVD_ERR_INVALID_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
