@@ -19,7 +19,8 @@ def declared_symbols():
 def test_header_declares_the_path():
     syms = declared_symbols()
     for need in ("mvd_sweep_corr_f32", "mvd_fuse_views_f32", "mvd_warp_variance_f32", "mvd_conv3d_bn_relu_f32",
-                 "mvd_softmax_regress_f32", "mvd_version", "mvd_last_error"):
+                 "mvd_softmax_regress_f32", "mvd_conv2d_bn_relu_f32", "mvd_pack_conv2d_weights_f32", "mvd_bias_leaky_relu_f32",
+                 "mvd_version", "mvd_last_error"):
         assert need in syms
 
 
