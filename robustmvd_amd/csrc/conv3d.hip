@@ -1228,12 +1228,18 @@ static int launch_deconv_all(const ConvParams& p0, hipStream_t st) {
 // of a 4 x 64 tile resident in LDS (48-B pixels: conflict-free ds_read_b128 across consecutive columns), the
 // 216 weights through the scalar cache.  packed weights here are [tap 27][cin 8].
 constexpr int C8_DZ = 16;  // output planes a workgroup of the 8 -> 1 kernel walks
+constexpr int C8_TW = 62;  // output columns per tile row: 64 slab columns (one per lane) minus the two halo columns
 __global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
     // depth-marching like conv3d_march_kernel: 3 input planes of the 4 x 64 tile in an LDS ring, the next plane
     // prefetched into registers while the current output plane is computed
-    constexpr int CIN = 8, TW = 64, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR;
+    // Lane l owns slab COLUMN l (input pixel c0 - 1 + l) and, for l = 1..62, output column c0 + l - 1.  Instead of reading
+    // its three kw-neighbours' pixels from LDS, a lane forms the three partial sums Q_kw = sum_{kd,kh,c} W[kd,kh,kw,c] *
+    // x[own pixel] and the output is Q_0[l-1] + Q_1[l] + Q_2[l+1]: one pixel read per (kd,kh) instead of three (the LDS
+    // pipe bounded this kernel) at the price of two lane shifts per output voxel and 62-wide tiles.
+    constexpr int CIN = 8, TW = C8_TW, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR;
+    static_assert(COLS == 64, "one slab column per lane");
     constexpr int NEL = ROWS * COLS * 2, NPF = (NEL + 255) / 256, DZ = C8_DZ;
-    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 4];  // 57 KB + dummy slot
+    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 4];  // 55 KB + dummy slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx = blockIdx.x;
     const int tw = bx % p.tiles_w; bx /= p.tiles_w;
@@ -1280,40 +1286,46 @@ __global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
     store_plane(z0 % 3);
     load_plane(z0 + 1);
 
-    const int orow = r0 + wave, ocol = c0 + lane;
-    const bool live = orow < p.ho && ocol < p.wo;
+    const int orow = r0 + wave, ocol = c0 + lane - 1;
+    const bool live = lane >= 1 && lane <= TW && orow < p.ho && ocol < p.wo;
     const float sc = p.scale[0], sh = p.shift[0];
     for (int z = z0; z < z1; ++z) {
         __syncthreads();
         store_plane((z + 1) % 3);
         __syncthreads();
         if (z + 1 < z1) load_plane(z + 2);
-        // four independent chains of packed FMAs: channel pairs (0,1) (2,3) (4,5) (6,7) as they sit in the 128-bit LDS
-        // reads (written with vector types: left to itself the vectoriser pairs channels across registers and spends
-        // three moves per packed FMA)
-        f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f}, acc45 = {0.f, 0.f}, acc67 = {0.f, 0.f};
+        // per kw two chains of packed FMAs over the channel pairs (0,1),(4,5) and (2,3),(6,7) as they sit in the 128-bit
+        // LDS reads (written with vector types: left to itself the vectoriser pairs channels across registers and
+        // spends three moves per packed FMA)
+        f32x2 qa[3], qb[3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { qa[kw] = f32x2{0.f, 0.f}; qb[kw] = f32x2{0.f, 0.f}; }
 #pragma unroll 1
-        for (int kd = 0; kd < 3; ++kd) {  // not unrolled: 36 LDS reads in flight per pass is all the register file takes
+        for (int kd = 0; kd < 3; ++kd) {  // not unrolled: bounded LDS reads / scalar loads in flight per pass
             const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;
-#pragma unroll 1
-            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const f32x4* sp = reinterpret_cast<const f32x4*>(slab + ((wave + kh) * COLS + lane) * PSTR);
+                const f32x4 a = sp[0], c = sp[1];
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const f32x4* sp = reinterpret_cast<const f32x4*>(slab + ((wave + kh) * COLS + lane + kw) * PSTR);
                     // constant address space: the loads are invariant for the compiler, so the (uniform) address goes
-                    // through the scalar cache and the weights arrive as SGPR-pair operands of the packed FMAs.  Every
-                    // (kd, kh) pass issues its 6 LDS reads and 3 scalar loads together and waits once, so sharing lgkmcnt
-                    // costs nothing — and the LDS pipe, which bounds this kernel, carries half the reads.
+                    // through the scalar cache and the weights arrive as SGPR-pair operands of the packed FMAs
                     typedef const __attribute__((address_space(4))) f32x4* cf4;
                     const cf4 wp = (cf4)(unsigned long long)(p.wpk + ((kd * 3 + kh) * 3 + kw) * 8);
-                    const f32x4 a = sp[0], c = sp[1], w0 = wp[0], w1 = wp[1];
-                    acc01 = __builtin_elementwise_fma(a.xy, w0.xy, acc01);
-                    acc23 = __builtin_elementwise_fma(a.zw, w0.zw, acc23);
-                    acc45 = __builtin_elementwise_fma(c.xy, w1.xy, acc45);
-                    acc67 = __builtin_elementwise_fma(c.zw, w1.zw, acc67);
+                    const f32x4 w0 = wp[0], w1 = wp[1];
+                    qa[kw] = __builtin_elementwise_fma(a.xy, w0.xy, qa[kw]);
+                    qb[kw] = __builtin_elementwise_fma(a.zw, w0.zw, qb[kw]);
+                    qa[kw] = __builtin_elementwise_fma(c.xy, w1.xy, qa[kw]);
+                    qb[kw] = __builtin_elementwise_fma(c.zw, w1.zw, qb[kw]);
                 }
+            }
         }
-        const float acc = ((acc01.x + acc01.y) + (acc23.x + acc23.y)) + ((acc45.x + acc45.y) + (acc67.x + acc67.y));
+        float q[3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) q[kw] = (qa[kw].x + qa[kw].y) + (qb[kw].x + qb[kw].y);
+        // output column o = pixel l takes kw = 0 from pixel l-1, kw = 1 from itself, kw = 2 from pixel l+1
+        const float acc = (__shfl_up(q[0], 1) + q[1]) + __shfl_down(q[2], 1);
         if (live) {
             const size_t o = (((size_t)b * p.Do + z) * p.ho + orow) * p.wo + ocol;
             float val = fmaf(acc, sc, sh);
@@ -1357,7 +1369,7 @@ static int launch_conv(const ConvParams& p0, hipStream_t st) {
 static int launch_c8_to_1(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     p.tiles_h = (p.ho + CONV_TH - 1) / CONV_TH;
-    p.tiles_w = (p.wo + 63) / 64;
+    p.tiles_w = (p.wo + C8_TW - 1) / C8_TW;
     const long long nblk = (long long)p.tiles_w * p.tiles_h * ((p.Do + C8_DZ - 1) / C8_DZ) * p.B;
     if (nblk > 0x7fffffffLL) {
         set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
