@@ -1229,17 +1229,19 @@ static int launch_deconv_all(const ConvParams& p0, hipStream_t st) {
 // 216 weights through the scalar cache.  packed weights here are [tap 27][cin 8].
 constexpr int C8_DZ = 16;  // output planes a workgroup of the 8 -> 1 kernel walks
 constexpr int C8_TW = 62;  // output columns per tile row: 64 slab columns (one per lane) minus the two halo columns
-__global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
+__global__ void __launch_bounds__(256, 4) conv3d_c8_to_1_kernel(ConvParams p) {
     // depth-marching like conv3d_march_kernel: 3 input planes of the 4 x 64 tile in an LDS ring, the next plane
     // prefetched into registers while the current output plane is computed
     // Lane l owns slab COLUMN l (input pixel c0 - 1 + l) and, for l = 1..62, output column c0 + l - 1.  Instead of reading
     // its three kw-neighbours' pixels from LDS, a lane forms the three partial sums Q_kw = sum_{kd,kh,c} W[kd,kh,kw,c] *
     // x[own pixel] and the output is Q_0[l-1] + Q_1[l] + Q_2[l+1]: one pixel read per (kd,kh) instead of three (the LDS
     // pipe bounded this kernel) at the price of two lane shifts per output voxel and 62-wide tiles.
-    constexpr int CIN = 8, TW = C8_TW, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN + CONV_PAD, SLAB = ROWS * COLS * PSTR;
+    // 32-byte LDS pixels (no padding: two-way bank conflicts on the few remaining reads) keep the ring at 37 KB, four
+    // workgroups per CU
+    constexpr int CIN = 8, TW = C8_TW, ROWS = CONV_TH + 2, COLS = TW + 2, PSTR = CIN, SLAB = ROWS * COLS * PSTR;
     static_assert(COLS == 64, "one slab column per lane");
     constexpr int NEL = ROWS * COLS * 2, NPF = (NEL + 255) / 256, DZ = C8_DZ;
-    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 4];  // 55 KB + dummy slot
+    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 4];  // 37 KB + dummy slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx = blockIdx.x;
     const int tw = bx % p.tiles_w; bx /= p.tiles_w;
@@ -1300,8 +1302,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_c8_to_1_kernel(ConvParams p) {
         f32x2 qa[3], qb[3];
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) { qa[kw] = f32x2{0.f, 0.f}; qb[kw] = f32x2{0.f, 0.f}; }
-#pragma unroll 1
-        for (int kd = 0; kd < 3; ++kd) {  // not unrolled: bounded LDS reads / scalar loads in flight per pass
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
             const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
