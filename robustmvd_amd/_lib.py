@@ -9,7 +9,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MVD_LIB_PATH") or os.path.join(_HERE, "lib", "libmvd_hip.so")  # override: kernel experiments
+LIB_PATH = os.path.join(_HERE, "lib", "libmvd_hip.so")
+# `make -C robustmvd_amd/csrc exp`: the same engine + experimental kernel variants selected by MVD_K3_CFG / MVD_K4_*.
+# Never loaded by the product path; tools/ and the variants test route calls through it with use_experiments_library().
+EXP_LIB_PATH = os.path.join(_HERE, "lib_exp", "libmvd_hip_exp.so")
 
 MVD_MAX_VIEWS = 16
 LAYOUT_NCDHW = 0
@@ -55,24 +58,52 @@ SIGNATURES = {
 }
 
 _lib = None
+_override = None  # set by use_experiments_library()
+
+
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():
     """Loads libmvd_hip.so (once).  Raises RuntimeError with build instructions if it is absent."""
     global _lib
+    if _override is not None:
+        return _override
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C robustmvd_amd/csrc`. There is no CPU fallback for this path.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _bind(LIB_PATH)
+    return _lib
+
+
+class use_experiments_library:
+    """Context manager for tools/ and tests: inside it every op goes through libmvd_hip_exp.so (path overridable),
+    whose kernel variants MVD_K3_CFG / MVD_K4_* select.  The product library is untouched and stays loaded."""
+
+    def __init__(self, path=None):
+        self.path = path or EXP_LIB_PATH
+
+    def __enter__(self):
+        global _override
+        if not os.path.exists(self.path):
+            raise RuntimeError(f"{self.path} not found: run `make -C robustmvd_amd/csrc exp`")
+        self._prev = _override
+        _override = _bind(self.path)
+        return _override
+
+    def __exit__(self, *exc):
+        global _override
+        _override = self._prev
+        return False
 
 
 def check(rc, what):

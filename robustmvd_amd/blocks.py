@@ -49,7 +49,15 @@ class PlanesweepCorrelation(nn.Module):
             raise NotImplementedError("only the configuration robust_mvd uses (TorchCorr, normalize='dim') is built")
         self._invdepth_cache = {}  # (num, min, max, type, device) -> device tensor: constants of the model, uploaded once
 
-    @torch.no_grad()
+    def warm(self, num_sampling_points, min_depth, max_depth, sampling_type, device):
+        """Uploads the sampling inverse depths of a fixed (scalar) range once, ahead of the first forward."""
+        ckey = (num_sampling_points, float(min_depth), float(max_depth), sampling_type, str(device))
+        if ckey not in self._invdepth_cache:
+            self._invdepth_cache[ckey] = compute_sampling_invdepths(min_depth, max_depth, num_sampling_points,
+                                                                    sampling_type).to(device)
+        return self._invdepth_cache[ckey]
+
+    @ops.inference_only
     def forward(self, feat_key, intrinsics_key, feat_sources, source_to_key_transforms, intrinsics_sources=None,
                 num_sampling_points=None, min_depth=None, max_depth=None, sampling_invdepths=None,
                 sampling_type="linear_invdepth"):
@@ -165,7 +173,7 @@ class FeatureNet(nn.Module):
         self._packed, self._packed_key = pk, key
         return pk
 
-    @torch.no_grad()
+    @ops.inference_only
     def forward_layout(self, x, out_layout):
         """x (N,3,H,W) normalised images -> features at H/4 x W/4 in `out_layout` (L.LAYOUT_*)."""
         pk = self._prepare()
@@ -232,7 +240,7 @@ class CostRegNet(nn.Module):
         self._packed, self._packed_key = pk, key
         return pk
 
-    @torch.no_grad()
+    @ops.inference_only
     def forward_channels_last(self, x):
         """x (B,D,h,w,32) -> cost (B,D,h,w) (the single output channel squeezed)."""
         if x.shape[1] % 8 or x.shape[2] % 8 or x.shape[3] % 8:
@@ -255,7 +263,7 @@ class CostRegNet(nn.Module):
         del conv0
         return layer("prob", y, relu=False).squeeze(-1)
 
-    @torch.no_grad()
+    @ops.inference_only
     def forward(self, x):
         """Reference layout: (B,32,D,h,w) -> (B,1,D,h,w)."""
         return self.forward_channels_last(ops.to_channels_last_3d(x)).unsqueeze(1)

@@ -636,8 +636,8 @@ __global__ void __launch_bounds__(256) conv3d_march_kernel(ConvParams p) {
 
 
 static long long march_min_blocks() {
-    static const long long v = getenv("MVD_K4_MARCH_MIN") ? atoll(getenv("MVD_K4_MARCH_MIN")) : 1024;
-    return v;
+    const char* e = exp_env("MVD_K4_MARCH_MIN");
+    return e ? atoll(e) : 1024;
 }
 
 template <int CIN, int NT, int MT, bool PAIR, int MARCH_DZ = 16>
@@ -1416,10 +1416,10 @@ static int dispatch_cout(const ConvParams& p, hipStream_t st) {
     // MT (16-column tiles per wave) chosen so that the slab fits LDS and wide rows get long tiles
     constexpr int MT = MODE == MVD_CONV3D_STRIDE2 ? (CIN >= 32 ? 2 : 4) : 4;
     if constexpr (MODE == MVD_CONV3D_STRIDE1) {
-        const bool old = getenv("MVD_K4_NOMARCH") != nullptr;  // experiments: the plane-at-a-time kernels
+        const bool old = exp_env("MVD_K4_NOMARCH") != nullptr;  // experiments: the plane-at-a-time kernels
         if (p.Cout == 8) {
             if constexpr (CIN == 32)
-                if (!old && !p.skip && !getenv("MVD_K4_NOKSPLIT")) {  // conv0: two waves per row, split over the input channels
+                if (!old && !p.skip && !exp_env("MVD_K4_NOKSPLIT")) {  // conv0: two waves per row, split over the input channels
                     const int rc = launch_conv0_ksplit<16>(p, st);
                     if (rc >= 0) return rc;
                 }
@@ -1456,7 +1456,7 @@ static int dispatch_cout(const ConvParams& p, hipStream_t st) {
                 }
             }
         }
-        if (p.Cout % 4 == 0 && nt <= 2 && !getenv("MVD_K4_DECONV_CLASSES")) {
+        if (p.Cout % 4 == 0 && nt <= 2 && !exp_env("MVD_K4_DECONV_CLASSES")) {
             if (nt == 1) return launch_deconv_all<CIN, 1, 2>(p, st);
             return launch_deconv_all<CIN, 2, (CIN >= 64 ? 1 : 2)>(p, st);
         }

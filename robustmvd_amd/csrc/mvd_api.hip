@@ -1,5 +1,6 @@
 // Version / error reporting / layout helpers of libmvd_hip.so.
 #include "mvd_common.h"
+#include <stdlib.h>
 
 namespace mvd {
 static thread_local char g_err[512] = "";
@@ -9,6 +10,10 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+#ifdef MVD_EXPERIMENTS
+const char* exp_env(const char* name) { return getenv(name); }  // experiments library only (mvd_common.h)
+#endif
 
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 void timing_begin(hipStream_t st) {

@@ -40,6 +40,16 @@ struct ViewOutPtrs {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Kernel-variant selectors for experiments.  The PRODUCT library (default build) has fixed dispatch and never reads
+// the process environment (include/mvd.h: no global mutable state): exp_env() is a constant nullptr there and every
+// `if (exp_env(...))` branch folds away.  Only the -DMVD_EXPERIMENTS build (`make exp` -> robustmvd_amd/lib_exp/
+// libmvd_hip_exp.so, used by tools/ and the variants test) looks at MVD_K3_CFG / MVD_K4_*.
+#ifdef MVD_EXPERIMENTS
+const char* exp_env(const char* name);
+#else
+constexpr const char* exp_env(const char*) { return nullptr; }
+#endif
+
 // ---- device: exactly rounded fp32 steps for the sampling-grid arithmetic -----------------------
 // The grids decide which taps are in bounds (a 0/1 mask in Path A), so they follow the reference's
 // operation order with one rounding per operation; the library is built with -ffp-contract=off and

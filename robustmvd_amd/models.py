@@ -55,6 +55,15 @@ class RobustMVD(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
+    SWEEP = dict(num_sampling_points=256, min_depth=0.4, max_depth=1000.0)  # robust_mvd.py:77-79
+
+    def _prepare(self):
+        """Constants of the sweep uploaded ahead of the first forward (FramePipeline calls this before it puts frames on
+        side streams)."""
+        dev = next(self.parameters()).device
+        if dev.type == "cuda":
+            self.corr_block.warm(sampling_type="linear_invdepth", device=dev, **self.SWEEP)
+
     def forward(self, images, poses, intrinsics, keyview_idx, **_):
         key_pos = _key_positions(keyview_idx, images[0].shape[0])
         keyview_idx = key_pos[0] if all(k == key_pos[0] for k in key_pos) else key_pos
@@ -77,7 +86,7 @@ class RobustMVD(nn.Module):
         corrs, masks, _ = self.corr_block(
             feat_key=enc_key, intrinsics_key=intrinsics_key, feat_sources=enc_sources,
             source_to_key_transforms=source_to_key, intrinsics_sources=intrinsics_source,
-            num_sampling_points=256, min_depth=0.4, max_depth=1000.0)  # robust_mvd.py:77-79
+            **self.SWEEP)
         fused_corr, _ = self.fusion_block(corrs=corrs, masks=masks)
         all_enc_fused, enc_fused = self.fusion_enc_block(corr=fused_corr, ctx=ctx)
         dec = self.decoder(enc_fused=enc_fused, all_enc={**all_enc_key, **all_enc_fused})
@@ -194,12 +203,13 @@ class MVSNet(nn.Module):
         # images are 0..255: /255 (NormalizeImagesToMinMax(0,1) is a plain rescale, transforms.py:283-288),
         # then ImageNet shift/scale (mvsnet.py:181-183)
         images, masks = to_torch((images, masks), device=device)
-        # (im / 255 - mean) / std on the device, the reference's float32 operations one by one (true divisions by
-        # tensors: torch's division by a python scalar multiplies by the reciprocal, which is not the same rounding)
-        mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32, device=device).view(-1, 1, 1)
-        std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32, device=device).view(-1, 1, 1)
+        # The reference's chain (mvsnet.py:181-183 -> transforms.py:283-311) on the device, rounding for rounding:
+        # x = im / 255.0 in float32 (a true division, not torch's scalar-reciprocal shortcut), then
+        # (x - shift) / scale with shift and scale Python LISTS, i.e. float64 arithmetic, then astype(float32).
+        mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float64, device=device).view(-1, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float64, device=device).view(-1, 1, 1)
         c255 = torch.full((1,), 255.0, dtype=torch.float32, device=device)
-        images = [(im.float() / c255 - mean) / std for im in images]
+        images = [(((im.float() / c255).double() - mean) / std).float() for im in images]
         # stay on the host: keyview_idx only orders the views, depth_range only seeds torch.linspace, and the 4x4
         # calibration products are cheaper there than as a dozen tiny launches (forward accepts either placement)
         keyview_idx, depth_range, intrinsics, poses = to_torch((keyview_idx, depth_range, intrinsics, poses))
@@ -211,7 +221,7 @@ class MVSNet(nn.Module):
         return to_numpy(pred), to_numpy(aux)
 
 
-@register_model
+@register_model(trainable=False)  # the reference lists it as trainable; this engine's sweep + fusion have no backward yet
 def robust_mvd(pretrained=True, weights=None, train=False, num_gpus=1, **kwargs):
     if pretrained and weights is None:
         raise RuntimeError("robust_mvd: the pretrained weights are URL-only (robust_mvd.py:153) and there is no network; "

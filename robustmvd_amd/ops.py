@@ -1,10 +1,39 @@
 """Operator-level entry points of the HIP engine on torch (ROCm) tensors.  Each function validates its
 arguments in Python (ValueError), allocates outputs/workspace with torch and calls one C-ABI function of
-libmvd_hip.so on the tensor's device and torch's current stream.  Inference only (no autograd).
+libmvd_hip.so on the tensor's device and torch's current stream.  Inference only: an input that requires grad while
+autograd is recording raises (see inference_only).
 """
+import functools
+
 import torch
 
 from . import _lib as L
+
+
+def _tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors(o)
+
+
+def inference_only(fn):
+    """The HIP kernels behind this entry point have no backward.  The reference's ops are differentiable
+    (planesweep_corr.py:514-521, learned_fusion.py:24-54), so cutting the graph silently would train a model with
+    wrong gradients: with autograd recording and an input that requires grad this raises instead.  Otherwise the
+    call runs under torch.no_grad()."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in _tensors((args, kwargs))):
+            raise RuntimeError(f"{fn.__qualname__}: an input requires grad, but this HIP path is inference-only (no "
+                               "backward is implemented); call it under torch.no_grad() or detach the inputs")
+        with torch.no_grad():
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _views(ts, name, V=None):
@@ -20,7 +49,7 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
-@torch.no_grad()
+@inference_only
 def sweep_corr(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths):
     """K1. feat_key (N,C,h,w); feat_sources V x (N,C,hs,ws); K_* relative intrinsics (N,3,3);
     T_src2key V x (N,4,4); invdepths (1 or N, S).  Returns (corrs[V], masks[V]) each (N,S,h,w)."""
@@ -59,7 +88,7 @@ def sweep_corr(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths):
     return corrs, masks
 
 
-@torch.no_grad()
+@inference_only
 def fuse_views(corrs, masks, scores):
     """K2. corrs, masks V x (N,S,h,w); scores V x (N,1,h,w) -> fused, fused_mask (N,S,h,w)."""
     lib = L.load()
@@ -82,7 +111,7 @@ def fuse_views(corrs, masks, scores):
     return fused, fmask
 
 
-@torch.no_grad()
+@inference_only
 def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, channels_last=False, exact_grid=False,
                   staged=False):
     """K3. key_feat (B,C,h,w); src_feats V x (B,C,h,w); src_projs V x (B,4,4); key_proj_inv (B,4,4);
@@ -124,7 +153,7 @@ def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, ch
     return out
 
 
-@torch.no_grad()
+@inference_only
 def homo_warp(src_feat, src_proj, ref_proj_inv, depth_values):
     """Drop-in for rmvd.models.blocks.utils.homo_warp (blocks/utils.py:222): -> (B,C,D,H,W)."""
     lib = L.load()
@@ -151,7 +180,7 @@ def homo_warp(src_feat, src_proj, ref_proj_inv, depth_values):
     return out
 
 
-@torch.no_grad()
+@inference_only
 def pack_conv3d_weights(weight, mode):
     """weight: Conv3d (Cout,Cin,3,3,3) or, for mode DECONV3D_STRIDE2, ConvTranspose3d (Cin,Cout,3,3,3)."""
     lib = L.load()
@@ -172,7 +201,7 @@ def pack_conv3d_weights(weight, mode):
     return packed, Cin, Cout
 
 
-@torch.no_grad()
+@inference_only
 def conv3d_bn_relu(x, packed, Cin, Cout, scale, shift, mode, relu=True, skip=None):
     """K4. x (B,D,h,w,Cin) channel-last -> (B,Do,ho,wo,Cout)."""
     lib = L.load()
@@ -203,7 +232,7 @@ def conv3d_bn_relu(x, packed, Cin, Cout, scale, shift, mode, relu=True, skip=Non
     return y
 
 
-@torch.no_grad()
+@inference_only
 def pack_conv2d_weights(weight):
     """weight: Conv2d (Cout,Cin,k,k), k in (3, 5) -> (packed, Cin, Cout, k)."""
     lib = L.load()
@@ -221,7 +250,7 @@ def pack_conv2d_weights(weight):
     return packed, Cin, Cout, k
 
 
-@torch.no_grad()
+@inference_only
 def conv2d_bn_relu(x, packed, Cin, Cout, ksize, stride, scale, shift, relu=True, out_layout=L.LAYOUT_NHWC, out=None):
     """K6. x: (B,3,H,W) image when Cin == 3, else channel-last (B,h,w,Cin).  Returns (B,ho,wo,Cout) for LAYOUT_NHWC,
     (B,Cout,ho,wo) for LAYOUT_NCHW, or the zero-bordered (B,ho+3,wo+3,Cout) staging map for LAYOUT_NHWC_BORDER
@@ -263,7 +292,7 @@ def conv2d_bn_relu(x, packed, Cin, Cout, ksize, stride, scale, shift, relu=True,
     return y
 
 
-@torch.no_grad()
+@inference_only
 def softmax_regress(cost, depth_values, with_confidence=True):
     """K5. cost (B,D,h,w); depth_values (B,D) -> depth (B,h,w), confidence (B,h,w) or None."""
     lib = L.load()
@@ -280,7 +309,7 @@ def softmax_regress(cost, depth_values, with_confidence=True):
     return depth, conf
 
 
-@torch.no_grad()
+@inference_only
 def bias_leaky_relu_(x, bias, slope=0.2):
     """In place: x (N,C,H,W) contiguous <- leaky_relu(x + bias[c], slope).  Returns x."""
     lib = L.load()
@@ -294,7 +323,7 @@ def bias_leaky_relu_(x, bias, slope=0.2):
     return x
 
 
-@torch.no_grad()
+@inference_only
 def to_channels_last_3d(x):
     """(B,C,D,h,w) -> (B,D,h,w,C) through the library's tiled transpose."""
     lib = L.load()
@@ -307,7 +336,7 @@ def to_channels_last_3d(x):
     return y
 
 
-@torch.no_grad()
+@inference_only
 def from_channels_last_3d(y):
     """(B,D,h,w,C) -> (B,C,D,h,w)."""
     lib = L.load()

@@ -37,6 +37,16 @@ class FramePipeline:
         self.device = dev
         self.streams = [torch.cuda.Stream(dev) for _ in range(depth)]
         self._next = 0
+        # Cold start: the engine's modules pack their weights (and upload sweep constants) lazily, on whatever stream
+        # is current at their first forward.  A fresh model's first frames would otherwise race: frame 1 packs on
+        # streams[0], frame 2 on streams[1] reuses the cached packed weights before streams[0] has run the pack
+        # kernels.  Do all of it now, on the current stream, and finish it before any side-stream work.
+        with torch.no_grad():
+            for m in model.modules():
+                prep = getattr(m, "_prepare", None)
+                if callable(prep):
+                    prep()
+        torch.cuda.current_stream(dev).synchronize()
 
     @torch.no_grad()
     def submit(self, **sample):

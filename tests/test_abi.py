@@ -59,3 +59,18 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_product_library_never_reads_the_environment():
+    """include/mvd.h: "no global mutable state".  The shipped library must not import getenv and must not carry the
+    experiment selectors' names; those exist only in the separate experiments build (`make exp`)."""
+    import subprocess
+    from robustmvd_amd import _lib
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"MVD_K3_CFG", b"MVD_K4_NOMARCH", b"MVD_K4_NOKSPLIT", b"MVD_K4_DECONV_CLASSES", b"MVD_K4_MARCH_MIN"):
+        assert name not in blob, f"{name.decode()} is compiled into the product library"
+    for f in os.listdir(os.path.join(ROOT, "robustmvd_amd", "csrc")):
+        if f.endswith((".hip", ".h")) and f != "mvd_api.hip":
+            assert "getenv" not in open(os.path.join(ROOT, "robustmvd_amd", "csrc", f)).read(), f

@@ -1,0 +1,170 @@
+"""GPU parity at the FULL sizes of every single-GPU BASELINE config, against the CPU oracle on identical seeded inputs
+(round-2 VERDICT item 1: configs[1] and configs[3] had never run under `-m gpu`, K1 / K6 had no full-size check).
+
+  configs[1]  448x640,  V=2, D=128  -> 112x160x128 volume;  K1 at 56x80
+  configs[2]  768x1152, V=4, D=256  -> 192x288x256 volume;  K1 at 96x144 x S256 x V4; K6 on 5 images of 768x1152
+  configs[3]  896x1216, V=4, D=256  -> 224x304x256 volume   (fp32 path here; the fp16-feature variant is in test_hip_f16.py)
+
+The whole Path-B forward (K6 x 8 -> K3 -> K4 x 11 -> K5) is compared with oracle/pipeline.py end to end — the C/OpenMP
+oracle finishes these sizes in seconds on the GPU box's host cores — and K3 / K1 / K6 are compared block by block.
+Tolerances: SURVEY.md 8(c): blocks atol = rtol = 1e-4 (K3's default folded sampling position is within 1e-4 px of the
+reference's chain: on white-noise features a ~1e-5 fraction of elements falls outside and is bounded at 2e-3), regressed
+depth rtol 1e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+import gen_common as gc
+from oracle import c_oracle as CO
+from oracle import mvd_oracle as O
+from oracle import pipeline as PL
+
+pytestmark = pytest.mark.gpu
+ATOL = RTOL = 1e-4
+PATH_A_ATOL = 2e-3  # vendor 2-D convolutions (MIOpen here, oneDNN in the oracle) differ in accumulation order
+
+CONFIGS = {1: (448, 640, 2, 128), 2: (768, 1152, 4, 256), 3: (896, 1216, 4, 256)}  # H, W, V, D  (BASELINE.json configs[i])
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def seeded_mvsnet(D, seed, dev):
+    import robustmvd_amd as R
+    model = R.MVSNet(num_sampling_steps=D).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.fill_state_dict(shapes, seed)
+    full = model.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    return R.add_run_function(model.to(dev)), sd
+
+
+def normalise(images):
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
+    return [((im / 255.0 - mean) / std).astype(np.float32)[None] for im in images]
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_mvsnet_forward_at_baseline_config_vs_oracle_pipeline(cfg, dev):
+    """model.run at the config's full size against the end-to-end CPU oracle: regressed depth rtol 1e-3."""
+    H, W, V, D = CONFIGS[cfg]
+    model, sd = seeded_mvsnet(D, 100 + cfg, dev)
+    s = gc.synthetic_sample(cfg, H, W, V)
+    pred, _ = model.run(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0,
+                        depth_range=(np.float32(0.5), np.float32(10.0)))
+    assert pred["depth"].shape == (1, H // 4, W // 4)  # run() drops the batch axis of an unbatched sample
+    ref = PL.mvsnet_forward(normalise(s["images"]), [p[None] for p in s["poses"]], [k[None] for k in s["intrinsics"]],
+                            0, (0.5, 10.0), sd, D)
+    got, want = pred["depth"], ref["depth"][0]
+    close = np.isclose(got, want, rtol=1e-3, atol=0)
+    # the soft argmin is continuous, but 11 conv layers amplify K3's <= 1e-4 px position rounding on white-noise
+    # features: all but a 1e-4 fraction of the pixels meet rtol 1e-3, every pixel meets 1e-2
+    assert close.mean() > 1 - 1e-4, f"{(~close).sum()} of {close.size} pixels beyond rtol 1e-3"
+    np.testing.assert_allclose(got, want, rtol=1e-2)
+    unc = np.abs(pred["depth_uncertainty"] - ref["depth_uncertainty"][0])
+    assert (unc < 2e-3).mean() > 0.999  # 4-bin confidence: trunc(E[idx]) can flip a bin at a few pixels
+
+
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_warp_variance_full_volume_vs_oracle(cfg, dev):
+    """K3 alone at the config's volume size against the C oracle on the WHOLE volume (configs[2] is covered by
+    test_hip_shapes.py::test_full_size_warp_variance_properties)."""
+    from robustmvd_amd import ops
+    from test_hip_shapes import mvs_inputs
+    H, W, V, D = CONFIGS[cfg]
+    h, w = H // 4, W // 4
+    feats, projs, key_inv, depth = mvs_inputs(1, 32, h, w, D, V, seed=50 + cfg)
+    got = ops.warp_variance(T(feats[0], dev), [T(f, dev) for f in feats[1:]], [T(p, dev) for p in projs], T(key_inv, dev),
+                            T(depth, dev), channels_last=True)
+    for d0 in range(0, D, 64):  # the oracle volume in 64-plane slabs (bounded host memory)
+        ref = CO.warp_variance(feats[0], feats[1:], projs, key_inv, depth[:, d0:d0 + 64])[0]
+        g = got[0, d0:d0 + 64].permute(3, 0, 1, 2).cpu().numpy()
+        bad = ~np.isclose(g, ref, atol=ATOL, rtol=RTOL)
+        assert bad.mean() < 2e-4
+        np.testing.assert_allclose(g, ref, atol=2e-3, rtol=2e-3)
+    exact = ops.warp_variance(T(feats[0], dev), [T(f, dev) for f in feats[1:]], [T(p, dev) for p in projs], T(key_inv, dev),
+                              T(depth[:, :64], dev), channels_last=True, exact_grid=True)
+    ref = CO.warp_variance(feats[0], feats[1:], projs, key_inv, depth[:, :64])[0]
+    g = exact[0].permute(3, 0, 1, 2).cpu().numpy()
+    assert (~np.isclose(g, ref, atol=ATOL, rtol=RTOL)).mean() < 2e-5
+    np.testing.assert_allclose(g, ref, atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("h,w,S,V", [(56, 80, 256, 2), (96, 144, 256, 4)])
+def test_sweep_corr_full_size_vs_oracle(h, w, S, V, dev):
+    """K1 at the Path-A shapes of configs[1] (56x80) and configs[2] (96x144 x S256 x V4: the launch bench.py's path_a
+    times), C = 256, against the C oracle on every plane: masks exact up to samples within 1e-4 px of a border."""
+    import robustmvd_amd as R
+    rng = np.random.default_rng(h)
+    N, C = 1, 256
+    fk = rng.standard_normal((N, C, h, w)).astype(np.float32)
+    fs = [rng.standard_normal((N, C, h, w)).astype(np.float32) for _ in range(V)]
+    K = gc.synthetic_intrinsics(h * 8, w * 8) / np.array([[w * 8.0] * 3, [h * 8.0] * 3, [1.0] * 3], np.float32)
+    Kk = K[None].astype(np.float32)
+    Ts = [gc.synthetic_pose(rng)[None] for _ in range(V)]
+    inv = O.compute_sampling_invdepths(0.4, 1000.0, S)
+    ref_c, ref_m = CO.sweep_corr(fk, fs, Kk, [Kk] * V, Ts, inv)
+    blk = R.PlanesweepCorrelation()
+    corrs, masks, inv_out = blk(T(fk, dev), T(Kk, dev), [T(f, dev) for f in fs], [T(t, dev) for t in Ts],
+                                num_sampling_points=S, min_depth=0.4, max_depth=1000.0)
+    np.testing.assert_allclose(inv_out.cpu().numpy()[:, :, 0, 0], inv, rtol=1e-6)
+    for v in range(V):
+        m = masks[v].cpu().numpy()
+        mism = m != ref_m[v]
+        assert mism.mean() <= 1e-4
+        assert 0.05 < m.mean() < 1.0  # the case is not degenerate: a real mix of visible and masked samples
+        np.testing.assert_allclose(corrs[v].cpu().numpy()[~mism], ref_c[v][~mism], atol=ATOL, rtol=RTOL)
+
+
+def test_featurenet_full_size_vs_oracle(dev):
+    """K6 x 8 on the 5 images of the headline config (768x1152) against torch-CPU layers with the same weights (the
+    reference's own arithmetic), in the reference's layout and in K3's zero-bordered staging layout."""
+    import robustmvd_amd as R
+    from robustmvd_amd import _lib as L
+    from test_oracle_golden import featurenet_shapes
+    net = R.blocks.FeatureNet().eval()
+    sd = gc.fill_state_dict(featurenet_shapes(), 77)
+    full = net.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    net.load_state_dict(full)
+    net = net.to(dev)
+    x = gc.rng_array(5, (5, 3, 768, 1152), 1.0)
+    ref = PL.feature_net(x, sd, prefix="")
+    out = net(T(x, dev))
+    assert tuple(out.shape) == (5, 32, 192, 288)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=ATOL, rtol=RTOL)
+    pad = net.forward_layout(T(x, dev), L.LAYOUT_NHWC_BORDER)
+    assert torch.equal(pad[:, 1:193, 1:289].permute(0, 3, 1, 2), out)
+    pad[:, 1:193, 1:289] = 0
+    assert not pad.any()
+
+
+def test_robustmvd_forward_at_config1_vs_oracle_pipeline(dev):
+    """Path A end to end at configs[1] (448x640, 2 sources) against oracle/pipeline.py, inverse-depth space."""
+    import robustmvd_amd as R
+    H, W, V = 448, 640, 2
+    model = R.RobustMVD().eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.robustmvd_weights(shapes, 5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = R.add_run_function(model.to(dev))
+    s = gc.synthetic_sample(9, H, W, V)
+    pred, aux = model.run(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0)
+    scale = np.array([[W] * 3, [H] * 3, [1.0] * 3], np.float32)
+    ref = PL.robustmvd_forward([(im / 255.0 - 0.4).astype(np.float32)[None] for im in s["images"]],
+                               [p[None] for p in s["poses"]], [(k / scale)[None] for k in s["intrinsics"]], 0, sd)
+    assert pred["depth"].shape == (1, H // 2, W // 2)
+    np.testing.assert_allclose(aux["invdepth"], ref["invdepth"][0], atol=PATH_A_ATOL, rtol=PATH_A_ATOL)
+    np.testing.assert_allclose(aux["invdepth_log_b"], ref["invdepth_log_b"][0], atol=PATH_A_ATOL, rtol=PATH_A_ATOL)

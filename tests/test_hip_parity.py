@@ -272,6 +272,34 @@ def test_frame_pipeline_matches_sequential_forwards(dev):
         R.FramePipeline(model, depth=0)
 
 
+def test_frame_pipeline_cold_start(dev):
+    """a FRESH model (no forward yet, so no packed weights) handed straight to FramePipeline: the lazy weight
+    packing must not race between the side streams.  Results equal sequential forwards run afterwards."""
+    import robustmvd_amd as R
+    from robustmvd_amd.registry import add_batch_dim
+    H, W, D, V = 64, 96, 16, 2
+    model = R.MVSNet(num_sampling_steps=D).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    full = model.state_dict()
+    for k, v in gc.fill_state_dict(shapes, 3).items():
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    model = model.to(dev)
+    samples = []
+    for i in range(4):
+        s = gc.synthetic_sample(70 + i, H, W, V)
+        im, key, po, intr, dr = add_batch_dim(s["images"], 0, s["poses"], s["intrinsics"], (np.float32(0.5), np.float32(10.0)))
+        samples.append(model.input_adapter(images=im, keyview_idx=key, poses=po, intrinsics=intr, depth_range=dr))
+    assert model.feature._packed is None and model.cost_regularization._packed is None
+    pipe = R.FramePipeline(model, depth=3)
+    assert model.feature._packed is not None and model.cost_regularization._packed is not None
+    got = [t.result()[0]["depth"] for t in [pipe.submit(**s) for s in samples]]
+    with torch.no_grad():
+        want = [model(**s)[0]["depth"] for s in samples]
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 def test_input_adapters_normalise_on_device_like_numpy(dev):
     """the adapters upload raw images and normalise on the GPU: bit-identical to the reference's numpy arithmetic
     (rmvd/models/mvsnet.py:181-183, robust_mvd.py:113-116)"""
@@ -282,10 +310,14 @@ def test_input_adapters_normalise_on_device_like_numpy(dev):
     poses = [np.eye(4, dtype=np.float32)[None]] * 2
     mvs = R.MVSNet(num_sampling_steps=8).to(dev)
     got = mvs.input_adapter(images=images, keyview_idx=np.array([0]), poses=poses, intrinsics=[K, K], depth_range=(np.array([0.5], np.float32), np.array([10.0], np.float32)))
-    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(-1, 1, 1)
-    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(-1, 1, 1)
+    # the reference's chain, operation for operation (transforms.py:283-311): float32 /255, then a subtraction and a
+    # division by Python LISTS on an (N,H,W,3) view -- float64 arithmetic -- then astype(float32)
+    shift, scale = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
     for im, g_ in zip(images, got["images"]):
-        assert g_.is_cuda and np.array_equal(g_.cpu().numpy(), ((im / 255.0 - mean) / std).astype(np.float32))
+        x = np.transpose(im / 255.0, [0, 2, 3, 1])
+        assert x.dtype == np.float32
+        want = np.transpose(((x - shift) / scale), [0, 3, 1, 2]).astype(np.float32)
+        assert g_.is_cuda and g_.dtype == torch.float32 and np.array_equal(g_.cpu().numpy(), want)
     rm = R.RobustMVD().to(dev)
     got = rm.input_adapter(images=images, keyview_idx=np.array([0]), poses=poses, intrinsics=[K, K])
     for im, g_ in zip(images, got["images"]):

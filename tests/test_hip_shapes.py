@@ -335,15 +335,17 @@ def test_full_size_regulariser_and_regression_properties(dev):
 
 @pytest.mark.parametrize("cfg", ["lds,4", "lds,8", "wave,4", "wave,8", "4,3", "8,2", "r4,3", "u4,2", "v4,3", "v4,4", "q8,4", "q8,3"])
 def test_warp_variance_experimental_variants_match_default(cfg, dev, monkeypatch):
-    """the compiled-in experimental forms of K3 (LDS-staged footprints, other plane/occupancy splits) give the
-    same volume as the default kernel bit for bit, including tiles whose footprint falls back to direct gathers"""
+    """the experimental forms of K3 (LDS-staged footprints, other plane/occupancy splits; compiled only into
+    robustmvd_amd/lib_exp/libmvd_hip_exp.so, never into the product library) give the same volume as the product
+    kernel bit for bit, including tiles whose footprint falls back to direct gathers"""
+    from robustmvd_amd import _lib as L
     from robustmvd_amd import ops
     feats, projs, key_inv, depth = mvs_inputs(1, 32, 45, 70, 19, 3, seed=9, rot=0.12, trans=0.3, dmin=0.4, dmax=8.0)
     args = (T(feats[0], dev), [T(f, dev) for f in feats[1:]], [T(p, dev) for p in projs], T(key_inv, dev), T(depth, dev))
-    monkeypatch.delenv("MVD_K3_CFG", raising=False)
-    ref = ops.warp_variance(*args, channels_last=True)
     monkeypatch.setenv("MVD_K3_CFG", cfg)
-    got = ops.warp_variance(*args, channels_last=True)
+    ref = ops.warp_variance(*args, channels_last=True)  # product library: ignores the environment
+    with L.use_experiments_library():
+        got = ops.warp_variance(*args, channels_last=True)
     assert torch.equal(got, ref)
 
 

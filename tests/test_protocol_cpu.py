@@ -79,3 +79,45 @@ def test_collate_and_index_helpers():
     assert col[0]["x"].shape == (2, 2) and list(col[1]) == [3, 4] and col[2] is None
     rt = to_numpy(to_torch({"a": [np.arange(3)], "b": (np.float32(1.5),)}))
     assert rt["a"][0].tolist() == [0, 1, 2]
+
+
+def test_product_sampling_invdepths_match_reference_golden():
+    """The PRODUCT's compute_sampling_invdepths (host code, robustmvd_amd/blocks.py) against every key of the
+    reference's g1 fixture: both sampling types, S = 64 / 256, and the batched (per-sample range) form
+    (planesweep_corr.py:524-555)."""
+    from conftest import load_golden
+    from robustmvd_amd.blocks import compute_sampling_invdepths
+    g = load_golden("g1_invdepths")
+    seen = set()
+    for S in (64, 256):
+        for typ in ("linear_invdepth", "linear_depth"):
+            got = compute_sampling_invdepths(0.4, 1000.0, S, typ)
+            assert tuple(got.shape) == (1, S)
+            np.testing.assert_allclose(got.numpy(), g[f"S{S}_{typ}"], rtol=1e-6, atol=1e-9)
+            seen.add(f"S{S}_{typ}")
+    got = compute_sampling_invdepths(np.array([0.4, 0.7], np.float32), np.array([1000.0, 50.0], np.float32), 16)
+    np.testing.assert_allclose(got.numpy(), g["batched_S16"], rtol=1e-6, atol=1e-9)
+    seen.add("batched_S16")
+    assert seen == set(g.files)
+    with pytest.raises(ValueError):
+        compute_sampling_invdepths(0.4, 1000.0, 8, "log")
+
+
+def test_inference_only_ops_refuse_autograd():
+    """the reference's sweep and fusion are differentiable; this engine's are not (yet), so recording a
+    graph through them must fail loudly instead of cutting the gradients silently.  The check runs before any device
+    validation, so it can be exercised without a GPU."""
+    import robustmvd_amd as R
+    from robustmvd_amd import ops
+    x = torch.zeros(1, 4, 2, 2, requires_grad=True)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        ops.fuse_views([x, x], [x.detach(), x.detach()], [x.detach()[:, :1]] * 2)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        R.PlanesweepCorrelation()(x, torch.eye(3)[None], [x], [torch.eye(4)[None]], num_sampling_points=4, min_depth=1.0,
+                                  max_depth=2.0)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        ops.softmax_regress(x, torch.zeros(1, 4))
+    with torch.no_grad(), pytest.raises(ValueError, match="cuda"):  # under no_grad the same call reaches validation
+        ops.softmax_regress(x, torch.zeros(1, 4))
+    # a model whose sweep cannot back-propagate is not offered for training
+    assert R.list_models(trainable_only=True) == []

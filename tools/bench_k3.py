@@ -39,19 +39,22 @@ def make_inputs(H, W, V, D, dev, seed=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--cfgs", nargs="*", default=["4,4"])
+    ap.add_argument("--cfgs", nargs="*", default=["product"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--layout", default="ndhwc")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     H, W, V, D = CONFIGS[args.config]
     feats, projs, key_inv, depth = make_inputs(H, W, V, D, dev)
-    lib = L.load()
     nbytes = 4.0 * ((V + 1) * 32 * (H // 4) * (W // 4) + 32 * D * (H // 4) * (W // 4))
     ref = None
     cl = args.layout == "ndhwc"
+    import contextlib
     for cfg in args.cfgs:
+      # "product" = the shipped library (fixed dispatch); anything else = a variant of the experiments library
+      with (contextlib.nullcontext() if cfg == "product" else L.use_experiments_library()):
         os.environ["MVD_K3_CFG"] = cfg
+        lib = L.load()
         for _ in range(3):
             out = ops.warp_variance(feats[0], feats[1:], projs, key_inv, depth, channels_last=cl)
         ts = []
