@@ -448,6 +448,224 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// K3, round-2 form ("located"): C = 32, channel-last output, folded grid arithmetic.
+//
+// What bounded the kernel above (profiles/r01_k3_uniform_pmc.txt): 273 M vector-ALU wave-instructions per launch
+// (the SIMDs 59 % VALU-busy) of which only 85 M are the bilinear/variance FMAs; the rest is the sampling-position
+// arithmetic — done by 8 lanes per pixel, i.e. twice per (pixel, plane, view) even with the quad sharing — plus 20
+// DPP broadcasts per view, at 148 VGPRs = 3 waves per SIMD, too few to cover the gather latency and the store
+// acknowledgements (the store stream by itself runs at 6.6 TB/s: profiles/r02_storebw.txt).
+//
+// Here a workgroup first LOCATES: thread t computes the position, cell offset and four bilinear weights of exactly
+// one (pixel, plane, view) combination per pass (32 pixels x 4 planes x V views = 128 V combinations, no redundancy,
+// view wave-uniform so the transform comes through the scalar cache) and parks them in LDS (20 B each).  After one
+// barrier the same threads BLEND as before — 8 lanes per pixel, 4 channels each — but read weights and offsets from
+// LDS (broadcast reads, no VALU) instead of computing and shuffling them, and keep at most three cells in flight
+// (gather_blend_4planes_lds) so that the kernel fits 128 VGPRs = 4 waves per SIMD.  Same arithmetic, operation for
+// operation, as warp_variance_kernel: results are bit-identical.
+template <int MASK, int I>
+__device__ __forceinline__ void blend_plane_lds(float4 (&s1)[4], float4 (&s2)[4], const float4 wq, const u32x4 (&f)[4]) {
+    const float w[4] = {wq.x, wq.y, wq.z, wq.w};
+    accumulate_cell(s1[I], s2[I], w, f);
+}
+
+// taps of one cell: nw at `o`, ne at +128 (folds into the instruction's immediate), sw / se one padded row further
+// (the row pitch rides in the scalar offset operand: no per-lane address arithmetic besides `o` itself)
+__device__ __forceinline__ void gather_cell_s(u32x4 (&f)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned o, unsigned rowb) {
+    f[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+    f[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 128u, 0, 0);
+    f[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, rowb, 0);
+    f[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 128u, rowb, 0);
+}
+
+template <int MASK, int KO = 0>
+__device__ __forceinline__ void gather_blend_4planes_lds(float4 (&s1)[4], float4 (&s2)[4], const float4* __restrict__ wl,
+                                                         const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb) {
+    constexpr bool G1 = MASK & 1, G2 = (MASK >> 1) & 1, G3 = (MASK >> 2) & 1;
+    auto gather_cell_s = [](u32x4 (&f)[4], __amdgpu_buffer_rsrc_t r, unsigned o, unsigned rb) {
+        if constexpr (KO & 2) {  // knock-out (experiments library only): taps from registers, no memory access
+            f[0] = u32x4{o, o + 1, o + 2, o + 3}; f[1] = u32x4{o + 4, o + 5, o + 6, o + 7};
+            f[2] = u32x4{o + rb, o + 9, o + 10, o + 11}; f[3] = u32x4{o + rb + 4, o + 13, o + 14, o + 15};
+        } else {
+            mvd::gather_cell_s(f, r, o, rb);
+        }
+    };
+    u32x4 a[4], b[4], c[4];  // three register sets
+    gather_cell_s(a, rsrc, off[0], rowb);
+    if constexpr (MASK == 7) {
+        gather_cell_s(b, rsrc, off[1], rowb);
+        gather_cell_s(c, rsrc, off[2], rowb);
+        const float4 w0 = wl[0], w1 = wl[32], w2 = wl[64], w3 = wl[96];  // LDS: lands long before the gathers do
+        blend_plane_lds<MASK, 0>(s1, s2, w0, a);
+        gather_cell_s(a, rsrc, off[3], rowb);  // into the set plane 0 just released
+        blend_plane_lds<MASK, 1>(s1, s2, w1, b);
+        blend_plane_lds<MASK, 2>(s1, s2, w2, c);
+        blend_plane_lds<MASK, 3>(s1, s2, w3, a);
+    } else {
+        // at most two of planes 1..3 re-gather: sets b and c take them in order
+        if constexpr (G1) gather_cell_s(b, rsrc, off[1], rowb);
+        if constexpr (G2) gather_cell_s(G1 ? c : b, rsrc, off[2], rowb);
+        if constexpr (G3) gather_cell_s((G1 || G2) ? c : b, rsrc, off[3], rowb);
+        const float4 w0 = wl[0], w1 = wl[32], w2 = wl[64], w3 = wl[96];
+        blend_plane_lds<MASK, 0>(s1, s2, w0, a);
+        const u32x4 (&p1)[4] = G1 ? b : a;
+        blend_plane_lds<MASK, 1>(s1, s2, w1, p1);
+        const u32x4 (&p2)[4] = G2 ? (G1 ? c : b) : p1;
+        blend_plane_lds<MASK, 2>(s1, s2, w2, p2);
+        const u32x4 (&p3)[4] = G3 ? ((G1 || G2) ? c : b) : p2;
+        blend_plane_lds<MASK, 3>(s1, s2, w3, p3);
+    }
+}
+
+// KO != 0 only in the experiments library: knock-out builds that time parts of the kernel (they compute wrong results):
+// 1 no locate arithmetic, 2 gathers replaced by register values, 4 no stores, 8 one view only
+template <int MINW, int KO = 0>
+__global__ void __launch_bounds__(256, MINW) warp_variance_located_kernel(WarpParams p) {
+    constexpr int DPB = 4, PPB = 32;
+    constexpr unsigned PIX = 128;
+    extern __shared__ __attribute__((aligned(16))) float4 lds_loc[];  // [V][4][32] float4 weights, then [V][4][32] u32 offsets
+    const int V = (KO & 8) ? 1 : p.V;
+    unsigned* __restrict__ lds_off = reinterpret_cast<unsigned*>(lds_loc + V * (DPB * PPB));
+
+    const int tid = threadIdx.x;
+    const int h = p.h, w = p.w, D = p.D;
+
+    // ---- decode the block index: xcd | (d-chunk fastest, then tile within the XCD's band, then batch) ----
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int dchunks = (D + DPB - 1) / DPB;
+    const int dc = j % dchunks; j /= dchunks;
+    const int tile_in = j % p.tiles_per_xcd;
+    const int b = j / p.tiles_per_xcd;
+    const int tile = xcd * p.tiles_per_xcd + tile_in;
+    if (tile >= p.tiles_x * h) return;  // block-uniform
+    const int y = tile / p.tiles_x;
+    const int x0 = (tile - y * p.tiles_x) * PPB;
+    const int d0 = dc * DPB;
+
+    const int W2 = w + 3;
+    const unsigned rowb = (unsigned)W2 * PIX;             // bytes per padded row
+    const unsigned img_bytes = (unsigned)(h + 3) * rowb;  // bytes per padded image
+
+    // ---- locate: one (pixel, plane, view) per thread and pass -------------------------------------------------
+    {
+        const int lpx = tid & 31, li = (tid >> 5) & 3;
+        const int xl = min(x0 + lpx, w - 1);
+        const float fx = (float)xl, fy = (float)y;
+        const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+        const float xhi = (float)w, yhi = (float)h;
+        const float W2f = (float)W2;
+        const float depth = p.depth[(size_t)b * D + min(d0 + li, D - 1)];
+        for (int v = __builtin_amdgcn_readfirstlane(tid >> 7); v < ((KO & 1) ? 0 : V); v += 2) {  // wave-uniform view
+            const float* __restrict__ M = p.M + ((size_t)v * p.B + b) * 12;       // scalar loads
+            const float ax = fmaf(M[0], fx, fmaf(M[1], fy, M[2]));
+            const float ay = fmaf(M[4], fx, fmaf(M[5], fy, M[6]));
+            const float az = fmaf(M[8], fx, fmaf(M[9], fy, M[10]));
+            const float X = fmaf(ax, depth, M[3]), Y = fmaf(ay, depth, M[7]), Z = fmaf(az, depth, M[11]);
+            const float rz = __builtin_amdgcn_rcpf(Z);
+            float ix = fmaf(X * rz, sx, -0.5f), iy = fmaf(Y * rz, sy, -0.5f);
+            ix = __builtin_amdgcn_fmed3f(ix, -1.0f, xhi);
+            iy = __builtin_amdgcn_fmed3f(iy, -1.0f, yhi);
+            const float xf = floorf(ix), yf = floorf(iy);
+            const float wx = ix - xf, wy = iy - yf;
+            const float ux = 1.0f - wx, uy = 1.0f - wy;
+            const int slot = (v * DPB + li) * PPB + lpx;
+            lds_loc[slot] = make_float4(ux * uy, wx * uy, ux * wy, wx * wy);
+            lds_off[slot] = (unsigned)(int)fmaf(yf, W2f, xf) * PIX;  // exact in fp32 (checked on the host)
+        }
+    }
+
+    // ---- blend: 8 lanes per pixel, 4 channels per lane ---------------------------------------------------------
+    const int q = tid & 7, px = tid >> 3;
+    const int xc = min(x0 + px, w - 1);
+    const unsigned org = rowb + PIX + (unsigned)q * 16;  // padded (1,1) + this lane's channel quad
+    float4 s1[DPB], s2[DPB];
+    {
+        const float4 k = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.key) + (size_t)b * img_bytes + org +
+                                                          (unsigned)y * rowb + (unsigned)xc * PIX);
+        const float4 k2 = make_float4(k.x * k.x, k.y * k.y, k.z * k.z, k.w * k.w);
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) { s1[i] = k; s2[i] = k2; }
+    }
+    __syncthreads();
+
+    // the next view's cell offsets and source pointer are fetched (LDS / scalar cache) under the current view's gathers
+    unsigned offn[DPB];
+    const char* srcn;
+    auto fetch_view = [&](int v) {
+        const unsigned* __restrict__ ol = lds_off + v * (DPB * PPB) + px;
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) offn[i] = ol[i * PPB];
+        srcn = reinterpret_cast<const char*>(p.src.p[v]);
+    };
+    fetch_view(0);
+    for (int v = 0; v < V; ++v) {
+        unsigned off[DPB];
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) off[i] = offn[i] + org;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(srcn + (size_t)b * img_bytes), 0, (int)img_bytes, 0x00020000);
+        const float4* __restrict__ wl = lds_loc + v * (DPB * PPB) + px;
+        fetch_view(min(v + 1, V - 1));
+        // wave-uniform re-gather pattern: bit i-1 set = some lane's 2x2 cell differs between plane i-1 and plane i
+        const unsigned mask = (__builtin_amdgcn_ballot_w64(off[1] != off[0]) != 0 ? 1u : 0u) |
+                              (__builtin_amdgcn_ballot_w64(off[2] != off[1]) != 0 ? 2u : 0u) |
+                              (__builtin_amdgcn_ballot_w64(off[3] != off[2]) != 0 ? 4u : 0u);
+        switch (mask) {
+            case 0: gather_blend_4planes_lds<0, KO>(s1, s2, wl, off, rsrc, rowb); break;
+            case 1: gather_blend_4planes_lds<1, KO>(s1, s2, wl, off, rsrc, rowb); break;
+            case 2: gather_blend_4planes_lds<2, KO>(s1, s2, wl, off, rsrc, rowb); break;
+            case 3: gather_blend_4planes_lds<3, KO>(s1, s2, wl, off, rsrc, rowb); break;
+            case 4: gather_blend_4planes_lds<4, KO>(s1, s2, wl, off, rsrc, rowb); break;
+            case 5: gather_blend_4planes_lds<5, KO>(s1, s2, wl, off, rsrc, rowb); break;
+            case 6: gather_blend_4planes_lds<6, KO>(s1, s2, wl, off, rsrc, rowb); break;
+            default: gather_blend_4planes_lds<7, KO>(s1, s2, wl, off, rsrc, rowb); break;
+        }
+    }
+
+    const float inv_nv = 1.0f / (float)(p.V + 1);  // mvsnet.py:135, V there counts the key view
+    if (x0 + px < w) {
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) {
+            const int d = d0 + i;
+            if (d >= D) break;  // block-uniform
+            const float mx = s1[i].x * inv_nv, my = s1[i].y * inv_nv, mz = s1[i].z * inv_nv, mw = s1[i].w * inv_nv;
+            const float4 r = make_float4(fmaf(s2[i].x, inv_nv, -mx * mx), fmaf(s2[i].y, inv_nv, -my * my),
+                                         fmaf(s2[i].z, inv_nv, -mz * mz), fmaf(s2[i].w, inv_nv, -mw * mw));
+            if ((KO & 4) && r.x != 123.456f) continue;
+            *reinterpret_cast<float4*>(p.out + ((((size_t)b * D + d) * h + y) * w + (x0 + px)) * 32 + q * 4) = r;
+        }
+    }
+}
+
+static int launch_warp_located(const WarpParams& p0, hipStream_t st, int minw, int ko = 0) {
+    WarpParams p = p0;
+    p.tiles_x = (p.w + 31) / 32;
+    const long long tiles = (long long)p.tiles_x * p.h;
+    p.tiles_per_xcd = (int)((tiles + 7) / 8);
+    const long long nblk = 8LL * p.tiles_per_xcd * ((p.D + 3) / 4) * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("warp_variance: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    const size_t lds = (size_t)p.V * 4 * 32 * (sizeof(float4) + sizeof(unsigned));  // 2.5 KiB per view
+    timing_begin(st);
+#ifdef MVD_EXPERIMENTS
+    switch (ko) {
+#define MVD_KO(K) case K: hipLaunchKernelGGL((warp_variance_located_kernel<4, K>), dim3((unsigned)nblk), dim3(256), lds, st, p); break;
+        MVD_KO(1) MVD_KO(2) MVD_KO(4) MVD_KO(6) MVD_KO(7) MVD_KO(8) MVD_KO(14) MVD_KO(15)
+#undef MVD_KO
+        default: break;
+    }
+    if (ko == 0 && minw == 3) hipLaunchKernelGGL(warp_variance_located_kernel<3>, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    if (ko == 0 && minw != 3)
+#endif
+    hipLaunchKernelGGL(warp_variance_located_kernel<4>, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    timing_end(st);
+    return launch_status("warp_variance_located");
+}
+
 // (planes per workgroup, min waves per SIMD) — tuned on MI355X; MVD_K3_CFG="dpb,minw"
 // selects another compiled variant for experiments (C = 32 only).
 static void warp_cfg(int& dpb, int& minw, int& reuse) {
@@ -612,6 +830,14 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
     p.layout = layout & 0xff;
     p.exact_grid = (layout & MVD_GRID_EXACT) ? 1 : 0;
     if (!warp_only && C == 32 && p.layout == MVD_LAYOUT_NDHWC && !p.exact_grid) {
+        int located_minw = 4, ko = 0;
+#ifdef MVD_EXPERIMENTS
+        if (const char* e = exp_env("MVD_K3_CFG")) {
+            if (e[0] == 'L') sscanf(e, "L%d,%d", &located_minw, &ko);  // "L3" / "L4": occupancy; "L4,<ko>": knock-out build
+            else located_minw = 0;                                      // any other selector: the round-1 kernels
+        }
+#endif
+        if (located_minw) return launch_warp_located(p, st, located_minw, ko);
 #ifdef MVD_EXPERIMENTS
         // MVD_K3_CFG="lds,nd" selects the LDS-staged form (experiments library only)
         if (const char* e = exp_env("MVD_K3_CFG")) {
