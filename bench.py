@@ -36,6 +36,9 @@ CONFIGS = {  # BASELINE.json configs (index -> H, W, V, D)
     4: (704, 1280, 6, 512),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# untimed set-up forwards before the W warm-up steps of the contract (code objects, MIOpen solver search for path_a,
+# allocator and clocks to steady state); reported in the JSON line as `settle_forwards`
+SETTLE_FORWARDS = int(os.environ.get("MVD_BENCH_SETTLE", "12"))
 
 
 def build_mvsnet(D, dev, seed=0):
@@ -80,7 +83,7 @@ def timed_loop(model, samples, steps, warmup, world, dev, arm=None, cdev=None):
 
     # set-up, not measurement: the first calls load code objects, run MIOpen's solver search for the adjacent 2-D
     # convolutions and bring the allocator and the clocks to steady state; then the W warm-up steps of the contract
-    run(int(os.environ.get("MVD_BENCH_SETTLE", "12")), False)
+    run(SETTLE_FORWARDS, False)
     torch.cuda.synchronize(dev)
     run(warmup, False)
     return timed_region(lambda: run(steps, True), sync=lambda: torch.cuda.synchronize(dev),
@@ -103,31 +106,37 @@ def measured_copy_gbs(dev):
     return 2 * 4 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def cpu_baseline(H, W, V, D, sd, frames=3):
-    """The CPU oracle port (C/OpenMP hot path + torch-CPU 2-D feature net) on a bounded sample of the workload:
-    `frames` full frames (one forward each, 10-15 s of CPU work in total on the GPU box's host)."""
+def cpu_baseline(H, W, V, D, sd, frames=3, burn_in=1):
+    """The CPU oracle port (C/OpenMP hot path + torch-CPU 2-D feature net) on a bounded sample of the workload, with the
+    protocol of BASELINE.md section 3: `burn_in` discarded forward(s), then the MEDIAN of `frames` timed full frames
+    (one forward each; about 15-20 s of CPU work in total on the GPU box's host)."""
     from oracle import c_oracle as CO
     from oracle import pipeline as PL
     mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
     std = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
-    total, stages = 0.0, {}
-    for f in range(frames):
+    times, stages = [], {}
+    t_all = time.perf_counter()
+    for f in range(burn_in + frames):
         s = gc.synthetic_sample(f, H, W, V)
         images = [((im / 255.0 - mean) / std).astype(np.float32)[None] for im in s["images"]]
         timings = {}
         t0 = time.perf_counter()
         PL.mvsnet_forward(images, [p[None] for p in s["poses"]], [k[None] for k in s["intrinsics"]], 0, (0.5, 10.0), sd, D,
                           timings=timings)
-        total += time.perf_counter() - t0
+        if f < burn_in:
+            continue
+        times.append(time.perf_counter() - t0)
         for k, v in timings.items():
-            stages[k] = stages.get(k, 0.0) + v / frames
-    dt = total / frames
+            stages.setdefault(k, []).append(v)
+    total = time.perf_counter() - t_all
+    dt = float(np.median(times))
+    st = {k: float(np.median(v)) for k, v in stages.items()}
     return {"value": 1.0 / dt, "unit": "depth-maps/sec", "cores": CO.num_threads(), "kind": "port",
-            "sample": f"{frames} full frames {H}x{W} V{V} D{D} (one forward each, {total:.1f} s in total, {dt:.1f} s per frame; "
-                      f"oracle/pipeline.py: C/OpenMP warp+variance {stages['warp_variance']:.1f} s, CostRegNet "
-                      f"{stages['cost_reg']:.1f} s, soft-argmin {stages['regress']:.2f} s, torch-CPU FeatureNet "
-                      f"{stages['features']:.1f} s)",
-            "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()}
+            "sample": f"{burn_in} burn-in + {frames} timed full frames {H}x{W} V{V} D{D} (one forward each; median {dt:.2f} s per "
+                      f"frame, {total:.1f} s of CPU work in total; oracle/pipeline.py: C/OpenMP warp+variance "
+                      f"{st['warp_variance']:.2f} s, CostRegNet {st['cost_reg']:.2f} s, soft-argmin {st['regress']:.2f} s, "
+                      f"torch-CPU FeatureNet {st['features']:.2f} s)",
+            "times_s": [round(t, 3) for t in times], "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()}
 
 
 def main():
@@ -191,25 +200,32 @@ def main():
     value = world * args.steps / dt
 
     out = {
-        "metric": "depth-maps/sec at 768x1152x4srcx256planes; warp+aggregate HBM GB/s vs roofline",
+        # BASELINE.json's metric string, with the sizes of the config actually run (identical for the default config 2)
+        "metric": f"depth-maps/sec at {H}x{W}x{V}srcx{D}planes; warp+aggregate HBM GB/s vs roofline",
         "value": value, "unit": "depth-maps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "settle_forwards": SETTLE_FORWARDS,
         "config": {"workload": f"mvsnet (Path B) forward {H}x{W}, {V} source views, {D} planes, batch 1 per step "
                                f"(BASELINE.json configs[{args.config}])",
                    "parallelism": f"{world} independent replica(s), frames round-robin, no collectives"},
     }
     if rank == 0:
-        traffic = None
+        # `traffic` is NOT measured in this run: PMC counters need rocprofv3 passes of their own.  It is the constant
+        # the last committed counter passes gave for this config (profiles/k3_traffic.json, with its source files)
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "k3_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("config") == args.config:
                 traffic = tj.get("hbm_bytes_per_launch")
-        out["roofline"] = {"bound": "hbm", "kernel": "warp_variance_kernel (K3)", "achieved": k3_bytes / (k3_ms * 1e-3) / 1e9,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k3_bytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "traffic": traffic, "algorithmic_bytes_per_launch": k3_bytes, "avg_launch_ms": k3_ms,
-                           "launches_timed": args.steps, "measured_copy_peak_gbs": measured_copy_gbs(dev)}
+                traffic_src = "rocprofv3 PMC-derived constant, not measured in this run: " + str(tj.get("source", tpath))
+        copy_gbs = measured_copy_gbs(dev)
+        achieved = k3_bytes / (k3_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "warp_variance (K3)", "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": k3_bytes,
+                           "avg_launch_ms": k3_ms, "launches_timed": args.steps, "measured_copy_peak_gbs": copy_gbs,
+                           "frac_of_measured_copy": achieved / copy_gbs}
     # extra, not the headline: the same K steps with two frames in flight on separate HIP streams of this process
     # (kernels of one frame fill the matrix-pipe bubbles and tails of the other's); every step still is one batch-1
     # forward and all K complete inside the bracketed region

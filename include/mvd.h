@@ -182,6 +182,14 @@ int mvd_arm_kernel_timing(void* start_event, void* stop_event);
  * The convolutions themselves stay on the vendor library; this replaces the two elementwise passes after each. */
 int mvd_bias_leaky_relu_f32(float* x, const float* bias, int N, int C, long long HW, float slope, mvd_stream_t stream);
 
+/* Input resize of the model adapters: replaces ResizeInputs / UpscaleInputsToNextMultipleOf
+ * (rmvd/data/transforms.py:40-98, called from robust_mvd.py:104-113 and mvsnet.py:178), i.e.
+ * skimage.transform.resize(order=1) for UPSCALING (ho >= hi, wo >= wi): no anti-aliasing, float32 kept, mirror boundary,
+ * half-pixel centres, float64 interpolation — the arithmetic of scipy.ndimage.zoom(order=1, mode='mirror',
+ * grid_mode=True), which skimage delegates to.  src (planes,hi,wi) -> dst (planes,ho,wo); planes = N*C <= 65535. */
+int mvd_resize_order1_f32(const float* src, float* dst, long long planes, int hi, int wi, int ho, int wo,
+                          mvd_stream_t stream);
+
 /* layout helpers used at the operator-level boundary (reference tensors are NCHW / NCDHW) */
 int mvd_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);
 int mvd_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);

@@ -367,3 +367,58 @@ def softmax_regress(cost, depth_values):
     sum4 = pp[:, 0:D] + pp[:, 1:D + 1] + pp[:, 2:D + 2] + pp[:, 3:D + 3]  # p[j-1..j+2]
     conf = np.take_along_axis(sum4, np.clip(idx, 0, D - 1)[:, None], 1)[:, 0]
     return depth.astype(F32), conf.astype(F32), idx
+
+
+# ------------------------------------------------------------------------------------------------
+# Input resize of the adapters
+# ------------------------------------------------------------------------------------------------
+def _resize_axis_table(n_in, n_out):
+    """Per output index: (i0, i1, w0, w1) in float64 — scipy.ndimage.zoom's NI_ZoomShift with grid_mode=True,
+    mode='mirror', order=1: c = (o + 0.5) * n_in / n_out - 0.5, mirrored into [0, n_in - 1]."""
+    o = np.arange(n_out, dtype=np.float64)
+    if n_in <= 1:
+        z = np.zeros(n_out, np.int64)
+        return z, z, np.ones(n_out), np.zeros(n_out)
+    zoom = np.float64(n_in) / np.float64(n_out)
+    c = (o + 0.5) * zoom - 0.5
+    sz2 = 2 * n_in - 2
+    c = np.where(c < 0, -c, c)
+    c = np.where(c > n_in - 1, sz2 - c, c)
+    st = np.floor(c)
+    w1 = c - st
+    i0 = st.astype(np.int64)
+    i1 = i0 + 1
+    i1 = np.where(i1 > n_in - 1, sz2 - i1, i1)
+    return i0, i1, 1.0 - w1, w1
+
+
+def resize_order1(img, ht, wd):
+    """ResizeInputs' image branch (rmvd/data/transforms.py:64-66): skimage.transform.resize(image, (..., ht, wd), order=1)
+    for UPSCALING.  skimage is not installed here; for this case (no anti-aliasing because no axis shrinks, float32 kept,
+    clip a no-op for a convex combination, mode 'reflect' -> ndimage 'mirror') it delegates to
+    scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True), which IS installed and which tests/test_resize_cpu.py pins
+    this restatement against bit for bit.  img (..., H, W) float32 -> (..., ht, wd) float32."""
+    H, W = img.shape[-2:]
+    if ht < H or wd < W:
+        raise ValueError("resize_order1 restates the upscaling case only (downscaling adds skimage's Gaussian anti-aliasing)")
+    y0, y1, wy0, wy1 = _resize_axis_table(H, ht)
+    x0, x1, wx0, wx1 = _resize_axis_table(W, wd)
+    a = np.asarray(img, dtype=np.float32).astype(np.float64)
+    r0, r1 = a[..., y0, :], a[..., y1, :]
+    wy0, wy1 = wy0[:, None], wy1[:, None]
+    t = (r0[..., x0] * wy0) * wx0
+    t = t + (r0[..., x1] * wy0) * wx1
+    t = t + (r1[..., x0] * wy1) * wx0
+    t = t + (r1[..., x1] * wy1) * wx1
+    return t.astype(np.float32)
+
+
+def resize_inputs(images, intrinsics, ht, wd):
+    """ResizeInputs.__call__ (transforms.py:56-74): images resized with order 1, intrinsics scaled by
+    [[wd/orig_wd]*3, [ht/orig_ht]*3, [1]*3] as a float32 array."""
+    orig_ht, orig_wd = images[0].shape[-2:]
+    images = [resize_order1(im, ht, wd) for im in images]
+    if intrinsics is not None:
+        scale = np.array([[wd / orig_wd] * 3, [ht / orig_ht] * 3, [1.0] * 3], dtype=np.float32)
+        intrinsics = [k * scale for k in intrinsics]
+    return images, intrinsics

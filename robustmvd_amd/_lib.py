@@ -53,6 +53,7 @@ SIGNATURES = {
     "mvd_softmax_regress_f32": (_i, [_c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "mvd_bias_leaky_relu_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]),
     "mvd_arm_kernel_timing": (_i, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mvd_resize_order1_f32": (_i, [_c_float_p, _c_float_p, ctypes.c_longlong, _i, _i, _i, _i, ctypes.c_void_p]),
     "mvd_nchw_to_nhwc_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),
     "mvd_nhwc_to_nchw_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),
 }

@@ -639,6 +639,241 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_located_kernel(WarpPa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Marching form of the located kernel.  Knock-out timings of warp_variance_located_kernel (profiles/r02_k3_located_ko.txt)
+// show that nothing in it overlaps: 0.16 ms of per-workgroup prologue latency (kernel arguments -> depth -> locate ->
+// barrier), 0.10 ms of blend arithmetic per view, +0.15 ms of exposed gather latency, +0.17 ms of exposed store
+// acknowledgements add up linearly to the 0.82 ms.  Here a workgroup keeps its 32-pixel row segment and MARCHES through
+// `nch` consecutive 4-plane chunks: index decode and key fetch once, chunk c+1 is located (into the other half of a
+// double-buffered LDS table, depths through the scalar cache so that nothing queues behind the stores) before chunk c is
+// blended, one barrier per chunk, and the stores of chunk c drain while chunk c+1 is located and its first gathers fly.
+// NSETS = 2 keeps two cells in flight instead of three (96 VGPRs = 5 waves per SIMD).
+constexpr int cell_of(int mask, int i) { return i == 0 ? 0 : cell_of(mask, i - 1) + ((mask >> (i - 1)) & 1); }
+constexpr int ncells_of(int mask) { return cell_of(mask, 3) + 1; }
+constexpr int first_plane_of_cell(int mask, int k) {
+    for (int i = 0; i < 4; ++i)
+        if (cell_of(mask, i) == k) return i;
+    return 3;
+}
+
+template <int MASK, int K, int I>
+__device__ __forceinline__ void blend_if_cell(float4 (&s1)[4], float4 (&s2)[4], const float4 (&w)[4], const u32x4 (&X)[4],
+                                              const u32x4 (&Y)[4]) {
+    if constexpr (cell_of(MASK, I) == K) blend_plane_lds<MASK, I>(s1, s2, w[I], (K & 1) ? Y : X);
+}
+
+template <int MASK, int K>
+__device__ __forceinline__ void cell_step(float4 (&s1)[4], float4 (&s2)[4], const float4 (&w)[4], u32x4 (&X)[4], u32x4 (&Y)[4],
+                                          const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb) {
+    if constexpr (K < ncells_of(MASK)) {
+        blend_if_cell<MASK, K, 0>(s1, s2, w, X, Y);
+        blend_if_cell<MASK, K, 1>(s1, s2, w, X, Y);
+        blend_if_cell<MASK, K, 2>(s1, s2, w, X, Y);
+        blend_if_cell<MASK, K, 3>(s1, s2, w, X, Y);
+        if constexpr (K + 2 < ncells_of(MASK)) {  // the set this cell just released takes the cell after next
+            __builtin_amdgcn_sched_barrier(0);    // (left alone, the scheduler hoists these loads above the blends and spills)
+            gather_cell_s((K & 1) ? Y : X, rsrc, off[first_plane_of_cell(MASK, K + 2)], rowb);
+        }
+    }
+}
+
+template <int MASK>
+__device__ __forceinline__ void gather_blend_4planes_2sets(float4 (&s1)[4], float4 (&s2)[4], const float4* __restrict__ wl,
+                                                           const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb) {
+    u32x4 X[4], Y[4];
+    gather_cell_s(X, rsrc, off[0], rowb);
+    if constexpr (ncells_of(MASK) > 1) gather_cell_s(Y, rsrc, off[first_plane_of_cell(MASK, 1)], rowb);
+    const float4 w[4] = {wl[0], wl[32], wl[64], wl[96]};
+    cell_step<MASK, 0>(s1, s2, w, X, Y, off, rsrc, rowb);
+    cell_step<MASK, 1>(s1, s2, w, X, Y, off, rsrc, rowb);
+    cell_step<MASK, 2>(s1, s2, w, X, Y, off, rsrc, rowb);
+    cell_step<MASK, 3>(s1, s2, w, X, Y, off, rsrc, rowb);
+}
+
+template <int MINW, int NSETS>
+__global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpParams p, int nch) {
+    constexpr int DPB = 4, PPB = 32;
+    constexpr unsigned PIX = 128;
+    extern __shared__ __attribute__((aligned(16))) float4 lds_raw[];  // 2 x ([V][4][32] float4 weights + [V][4][32] u32 offsets)
+    const int V = p.V;
+    const int half_q = V * (DPB * PPB) * 5 / 4;  // float4 slots per table half (weights + offsets)
+
+    const int tid = threadIdx.x;
+    const int h = p.h, w = p.w, D = p.D;
+
+    // ---- decode the block index: xcd | (chunk group fastest, then tile within the XCD's band, then batch) ----
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int dchunks = (D + DPB - 1) / DPB;
+    const int dgroups = (dchunks + nch - 1) / nch;
+    const int dg = j % dgroups; j /= dgroups;
+    const int tile_in = j % p.tiles_per_xcd;
+    const int b = j / p.tiles_per_xcd;
+    const int tile = xcd * p.tiles_per_xcd + tile_in;
+    if (tile >= p.tiles_x * h) return;  // block-uniform
+    const int y = tile / p.tiles_x;
+    const int x0 = (tile - y * p.tiles_x) * PPB;
+    const int c_begin = dg * nch, c_end = min(c_begin + nch, dchunks);
+
+    const int W2 = w + 3;
+    const unsigned rowb = (unsigned)W2 * PIX;             // bytes per padded row
+    const unsigned img_bytes = (unsigned)(h + 3) * rowb;  // bytes per padded image
+    // constant address space: uniform reads of the depth samples and transforms become scalar-cache loads (lgkmcnt);
+    // as ordinary global loads they would be vector-memory operations that retire in order BEHIND the previous chunk's
+    // stores (profiles/r02_k3_march_pmc.txt: 17 vector loads per wave too many)
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* dvals = (cfloat*)(p.depth + (size_t)b * D);
+
+    // locate-phase constants: thread = (pixel lpx, plane li), views two at a time (wave-uniform)
+    const int lpx = tid & 31, li = (tid >> 5) & 3;
+    const float lfx = (float)min(x0 + lpx, w - 1), lfy = (float)y;
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float xhi = (float)w, yhi = (float)h;
+    const float W2f = (float)W2;
+    const int v_first = __builtin_amdgcn_readfirstlane(tid >> 7);
+    auto locate = [&](int c, int buf) {
+        float4* __restrict__ loc = lds_raw + buf * half_q;
+        unsigned* __restrict__ offs = reinterpret_cast<unsigned*>(loc + V * (DPB * PPB));
+        // the chunk's four depths are wave-uniform: scalar loads (lgkmcnt), so nothing here queues behind the
+        // vector-memory stores of the previous chunk
+        const int d0 = c * DPB;
+        const float e0 = dvals[min(d0, D - 1)], e1 = dvals[min(d0 + 1, D - 1)], e2 = dvals[min(d0 + 2, D - 1)],
+                    e3 = dvals[min(d0 + 3, D - 1)];
+        const float depth = li == 0 ? e0 : li == 1 ? e1 : li == 2 ? e2 : e3;
+        for (int v = v_first; v < V; v += 2) {
+            cfloat* M = (cfloat*)(p.M + ((size_t)v * p.B + b) * 12);  // scalar loads
+            const float ax = fmaf(M[0], lfx, fmaf(M[1], lfy, M[2]));
+            const float ay = fmaf(M[4], lfx, fmaf(M[5], lfy, M[6]));
+            const float az = fmaf(M[8], lfx, fmaf(M[9], lfy, M[10]));
+            const float X = fmaf(ax, depth, M[3]), Y = fmaf(ay, depth, M[7]), Z = fmaf(az, depth, M[11]);
+            const float rz = __builtin_amdgcn_rcpf(Z);
+            float ix = fmaf(X * rz, sx, -0.5f), iy = fmaf(Y * rz, sy, -0.5f);
+            ix = __builtin_amdgcn_fmed3f(ix, -1.0f, xhi);
+            iy = __builtin_amdgcn_fmed3f(iy, -1.0f, yhi);
+            const float xf = floorf(ix), yf = floorf(iy);
+            const float wx = ix - xf, wy = iy - yf;
+            const float ux = 1.0f - wx, uy = 1.0f - wy;
+            const int slot = (v * DPB + li) * PPB + lpx;
+            loc[slot] = make_float4(ux * uy, wx * uy, ux * wy, wx * wy);
+            offs[slot] = (unsigned)(int)fmaf(yf, W2f, xf) * PIX;  // exact in fp32 (checked on the host)
+        }
+    };
+
+    // blend-phase constants: 8 lanes per pixel, 4 channels per lane
+    const int q = tid & 7, px = tid >> 3;
+    const int xc = min(x0 + px, w - 1);
+    const unsigned org = rowb + PIX + (unsigned)q * 16;  // padded (1,1) + this lane's channel quad
+    // the key features of this thread's (pixel, channel quad) stay in LDS between chunks (4 fewer long-lived VGPRs)
+    float4* __restrict__ key_slot = lds_raw + 2 * half_q + tid;
+    *key_slot = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.key) + (size_t)b * img_bytes + org +
+                                                 (unsigned)y * rowb + (unsigned)xc * PIX);
+    const float inv_nv = 1.0f / (float)(V + 1);  // mvsnet.py:135, V there counts the key view
+    // stores: one descriptor per output plane (scalar arithmetic), one 32-bit offset per lane.  Inactive lanes (ragged
+    // right edge) carry pixel w-1 like the last active lane and store the same values to the same address: no divergent
+    // branch around the stores
+    const unsigned out_off = ((unsigned)y * (unsigned)w + (unsigned)xc) * 128u + (unsigned)q * 16u;
+    const size_t plane_bytes = (size_t)h * w * 128;
+
+    locate(c_begin, 0);
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c, buf ^= 1) {
+        __syncthreads();  // table `buf` is complete; every wave is done reading table `buf ^ 1`
+        if (c + 1 < c_end) locate(c + 1, buf ^ 1);
+        const float4* __restrict__ loc = lds_raw + buf * half_q;
+        const unsigned* __restrict__ offs = reinterpret_cast<const unsigned*>(loc + V * (DPB * PPB));
+        float4 s1[DPB], s2[DPB];
+        {
+            const float4 k = *key_slot;
+            const float4 k2 = make_float4(k.x * k.x, k.y * k.y, k.z * k.z, k.w * k.w);
+#pragma unroll
+            for (int i = 0; i < DPB; ++i) { s1[i] = k; s2[i] = k2; }
+        }
+        unsigned offn[DPB];
+        const char* srcn;
+        auto fetch_view = [&](int v) {
+            const unsigned* __restrict__ ol = offs + v * (DPB * PPB) + px;
+#pragma unroll
+            for (int i = 0; i < DPB; ++i) offn[i] = ol[i * PPB];
+            srcn = reinterpret_cast<const char*>(p.src.p[v]);
+        };
+        fetch_view(0);
+        for (int v = 0; v < V; ++v) {
+            unsigned off[DPB];
+#pragma unroll
+            for (int i = 0; i < DPB; ++i) off[i] = offn[i] + org;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(srcn + (size_t)b * img_bytes), 0, (int)img_bytes, 0x00020000);
+            const float4* __restrict__ wl = loc + v * (DPB * PPB) + px;
+            fetch_view(min(v + 1, V - 1));
+            const unsigned mask = (__builtin_amdgcn_ballot_w64(off[1] != off[0]) != 0 ? 1u : 0u) |
+                                  (__builtin_amdgcn_ballot_w64(off[2] != off[1]) != 0 ? 2u : 0u) |
+                                  (__builtin_amdgcn_ballot_w64(off[3] != off[2]) != 0 ? 4u : 0u);
+#define MVD_CASE(Mk)                                                                         \
+    if constexpr (NSETS == 2) gather_blend_4planes_2sets<Mk>(s1, s2, wl, off, rsrc, rowb); \
+    else gather_blend_4planes_lds<Mk>(s1, s2, wl, off, rsrc, rowb);                         \
+    break;
+            switch (mask) {
+                case 0: MVD_CASE(0)
+                case 1: MVD_CASE(1)
+                case 2: MVD_CASE(2)
+                case 3: MVD_CASE(3)
+                case 4: MVD_CASE(4)
+                case 5: MVD_CASE(5)
+                case 6: MVD_CASE(6)
+                default: MVD_CASE(7)
+            }
+#undef MVD_CASE
+        }
+        const int d0 = c * DPB;
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) {
+            if (d0 + i >= D) break;  // block-uniform (only in the last chunk of a D that is not a multiple of 4)
+            const float mx = s1[i].x * inv_nv, my = s1[i].y * inv_nv, mz = s1[i].z * inv_nv, mw = s1[i].w * inv_nv;
+            const float4 r = make_float4(fmaf(s2[i].x, inv_nv, -mx * mx), fmaf(s2[i].y, inv_nv, -my * my),
+                                         fmaf(s2[i].z, inv_nv, -mz * mz), fmaf(s2[i].w, inv_nv, -mw * mw));
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<char*>(p.out) + ((size_t)b * D + d0 + i) * plane_bytes, 0, (int)plane_bytes, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z),
+                                                         __float_as_uint(r.w)}, orsrc, out_off, 0, 0);
+        }
+    }
+}
+
+static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int nsets, int nch) {
+    WarpParams p = p0;
+    p.tiles_x = (p.w + 31) / 32;
+    const long long tiles = (long long)p.tiles_x * p.h;
+    p.tiles_per_xcd = (int)((tiles + 7) / 8);
+    const int dchunks = (p.D + 3) / 4;
+    if (nch < 1) nch = 1;
+    if ((long long)p.h * p.w * 128 >= 0x7fffffffLL) {  // one output plane is addressed through a 32-bit buffer offset
+        set_error("warp_variance: an output plane of %dx%dx32 floats exceeds the 2 GiB buffer-offset range", p.h, p.w);
+        return MVD_ERR_INVALID_ARG;
+    }
+    const int dgroups = (dchunks + nch - 1) / nch;
+    const long long nblk = 8LL * p.tiles_per_xcd * dgroups * p.B;
+    if (nblk > 0x7fffffffLL) {
+        set_error("warp_variance: %lld workgroups exceed the grid limit", nblk);
+        return MVD_ERR_INVALID_ARG;
+    }
+    const size_t lds = 2 * (size_t)p.V * 4 * 32 * (sizeof(float4) + sizeof(unsigned)) + 256 * sizeof(float4);  // 5 KiB per view + key
+    const dim3 grid((unsigned)nblk);
+    timing_begin(st);
+#define MVD_M(MW, NS) hipLaunchKernelGGL((warp_variance_march_kernel<MW, NS>), grid, dim3(256), lds, st, p, nch)
+    switch (minw * 10 + nsets) {
+#ifdef MVD_EXPERIMENTS
+        case 43: MVD_M(4, 3); break;
+        case 52: MVD_M(5, 2); break;
+        case 62: MVD_M(6, 2); break;
+#endif
+        default: MVD_M(4, 2); break;
+    }
+#undef MVD_M
+    timing_end(st);
+    return launch_status("warp_variance_march");
+}
+
 static int launch_warp_located(const WarpParams& p0, hipStream_t st, int minw, int ko = 0) {
     WarpParams p = p0;
     p.tiles_x = (p.w + 31) / 32;
@@ -833,10 +1068,17 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
         int located_minw = 4, ko = 0;
 #ifdef MVD_EXPERIMENTS
         if (const char* e = exp_env("MVD_K3_CFG")) {
-            if (e[0] == 'L') sscanf(e, "L%d,%d", &located_minw, &ko);  // "L3" / "L4": occupancy; "L4,<ko>": knock-out build
-            else located_minw = 0;                                      // any other selector: the round-1 kernels
+            if (e[0] == 'L') { sscanf(e, "L%d,%d", &located_minw, &ko); if (located_minw == 4 && ko == 0) ko = -1; }  // "L3"/"L4": the located kernel; "L4,<ko>": knock-out
+            else if (e[0] == 'M') {  // "M<minw>,<nsets>,<nch>": the marching form
+                int mw = 5, ns = 2, nc = 4;
+                sscanf(e, "M%d,%d,%d", &mw, &ns, &nc);
+                return launch_warp_march(p, st, mw, ns, nc);
+            } else located_minw = 0;                                    // any other selector: the round-1 kernels
         }
 #endif
+        // product: the marching form, 4 chunks per workgroup, two cells in flight, 4 waves per SIMD (tools/bench_k3.py)
+        if (ko < 0) return launch_warp_located(p, st, 4, 0);
+        if (located_minw == 4 && ko == 0 && (long long)p.h * p.w * 128 < 0x7fffffffLL) return launch_warp_march(p, st, 4, 2, 4);
         if (located_minw) return launch_warp_located(p, st, located_minw, ko);
 #ifdef MVD_EXPERIMENTS
         // MVD_K3_CFG="lds,nd" selects the LDS-staged form (experiments library only)

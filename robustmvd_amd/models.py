@@ -31,13 +31,24 @@ def _key_positions(keyview_idx, n):
     return [int(v) for v in k]
 
 
-def _require_multiple(images, m, what):
-    h, w = images[0].shape[-2:]
-    if h % m or w % m:
-        raise NotImplementedError(
-            f"{what}: input {h}x{w} is not a multiple of {m}. The reference resizes with skimage.transform.resize "
-            "(rmvd/data/transforms.py:56-74), which is not available here; resize the images (and scale the "
-            "intrinsics) before calling the model.")
+def _upscale_to_multiple(images, intrinsics, m, device):
+    """UpscaleInputsToNextMultipleOf(m) / the ResizeInputs call of robust_mvd.py:104-113 on the device (SURVEY.md 8f
+    rank 2).  images: list of (N,3,H,W) arrays or tensors in 0..255; intrinsics: list of (N,3,3) or None.  Uploads the
+    raw images, resizes them with the engine's order-1 kernel (ops.resize_order1: skimage.transform.resize's arithmetic
+    for upscaling) when H or W is not a multiple of m, and scales the intrinsics by [[wd/orig_wd]*3, [ht/orig_ht]*3,
+    [1]*3] in float32 like transforms.py:69-72.  Returns (device images, intrinsics, ht, wd)."""
+    orig_ht, orig_wd = images[0].shape[-2:]
+    ht, wd = int(math.ceil(orig_ht / m) * m), int(math.ceil(orig_wd / m) * m)
+    images = [im.float() for im in to_torch(list(images), device=device)]
+    if ht != orig_ht or wd != orig_wd:
+        if any(tuple(im.shape[-2:]) != (orig_ht, orig_wd) for im in images):
+            raise ValueError("all views must have the size of the first one to be resized together (transforms.py:56-66)")
+        images = [ops.resize_order1(im, ht, wd) for im in images]
+        if intrinsics is not None:
+            scale = np.array([[wd / orig_wd] * 3, [ht / orig_ht] * 3, [1.0] * 3], dtype=np.float32)
+            intrinsics = [(k.detach().cpu().numpy() if isinstance(k, torch.Tensor) else np.asarray(k)) * scale
+                          for k in intrinsics]
+    return images, intrinsics, ht, wd
 
 
 class RobustMVD(nn.Module):
@@ -99,16 +110,16 @@ class RobustMVD(nn.Module):
 
     def input_adapter(self, images, keyview_idx, poses, intrinsics, **_):
         device = get_torch_model_device(self)
-        _require_multiple(images, 64, "robust_mvd")
-        ht, wd = images[0].shape[-2:]
+        # resize to the next multiple of 64 if needed (robust_mvd.py:104-113), on the device
+        images, intrinsics, ht, wd = _upscale_to_multiple(images, intrinsics, 64, device)
         scale = np.array([[wd] * 3, [ht] * 3, [1.0] * 3], dtype=np.float32)  # relative intrinsics, :118-120
         intrinsics = [k / scale for k in intrinsics]
-        images, poses, intrinsics = to_torch((images, poses, intrinsics), device=device)
+        poses, intrinsics = to_torch((poses, intrinsics), device=device)
         keyview_idx = to_torch(keyview_idx)  # stays on the host: only used to order the views
         # im / 255 - 0.4 (robust_mvd.py:113-116) on the device: the raw images are uploaded, the arithmetic is the
         # reference's float32 operations one by one (true division by a tensor, not torch's scalar-reciprocal shortcut)
         c255 = torch.full((1,), 255.0, dtype=torch.float32, device=device)
-        images = [im.float() / c255 - 0.4 for im in images]
+        images = [im / c255 - 0.4 for im in images]
         poses = [p.float() for p in poses]
         intrinsics = [k.float() for k in intrinsics]
         return {"images": images, "keyview_idx": keyview_idx, "poses": poses, "intrinsics": intrinsics}
@@ -199,10 +210,11 @@ class MVSNet(nn.Module):
 
     def input_adapter(self, images, keyview_idx, poses=None, intrinsics=None, depth_range=None, masks=None):
         device = get_torch_model_device(self)
-        _require_multiple(images, 32, "mvsnet")
+        # UpscaleInputsToNextMultipleOf(32) (mvsnet.py:178), on the device
+        images, intrinsics, _, _ = _upscale_to_multiple(images, intrinsics, 32, device)
         # images are 0..255: /255 (NormalizeImagesToMinMax(0,1) is a plain rescale, transforms.py:283-288),
         # then ImageNet shift/scale (mvsnet.py:181-183)
-        images, masks = to_torch((images, masks), device=device)
+        masks = to_torch(masks, device=device)
         # The reference's chain (mvsnet.py:181-183 -> transforms.py:283-311) on the device, rounding for rounding:
         # x = im / 255.0 in float32 (a true division, not torch's scalar-reciprocal shortcut), then
         # (x - shift) / scale with shift and scale Python LISTS, i.e. float64 arithmetic, then astype(float32).

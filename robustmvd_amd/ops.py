@@ -324,6 +324,25 @@ def bias_leaky_relu_(x, bias, slope=0.2):
 
 
 @inference_only
+def resize_order1(images, ht, wd):
+    """images (..., H, W) fp32 device tensor -> (..., ht, wd): skimage.transform.resize(order=1) for upscaling
+    (rmvd/data/transforms.py:64-66), on the device (mvd_resize_order1_f32)."""
+    lib = L.load()
+    x = L.as_f32(images, "images")
+    if x.dim() < 2:
+        raise ValueError("images must be (..., H, W)")
+    hi, wi = x.shape[-2:]
+    if ht < hi or wd < wi:
+        raise ValueError(f"resize_order1: only upscaling is built ({hi}x{wi} -> {ht}x{wd})")
+    planes = x.numel() // (hi * wi)
+    y = torch.empty(tuple(x.shape[:-2]) + (ht, wd), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mvd_resize_order1_f32(L.ptr(x), L.ptr(y), planes, hi, wi, ht, wd, L.stream_of(x))
+    L.check(rc, "mvd_resize_order1_f32")
+    return y
+
+
+@inference_only
 def to_channels_last_3d(x):
     """(B,C,D,h,w) -> (B,D,h,w,C) through the library's tiled transpose."""
     lib = L.load()
