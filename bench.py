@@ -41,9 +41,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 SETTLE_FORWARDS = int(os.environ.get("MVD_BENCH_SETTLE", "12"))
 
 
-def build_mvsnet(D, dev, seed=0):
+# configs[3] is named "fp16 features" in BASELINE.json: features rounded to fp16, fp16 variance volume, regulariser's first
+# layer on fp16 MFMA (fp32 accumulation); every other config is fp32 end to end
+HALF_FEATURES = {3}
+
+
+def build_mvsnet(D, dev, seed=0, half_features=False):
     import robustmvd_amd as R
-    model = R.MVSNet(num_sampling_steps=D).eval()
+    model = R.MVSNet(num_sampling_steps=D, half_features=half_features).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = gc.fill_state_dict(shapes, seed)
     full = model.state_dict()
@@ -145,6 +150,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, help="index into BASELINE.json configs (default 2 = headline)")
+    ap.add_argument("--fp32", action="store_true", help="run configs[3] on the fp32 path instead of its named fp16-feature variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-path-a", action="store_true")
     args = ap.parse_args()
@@ -174,7 +180,8 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("MVD_BENCH_MIOPEN_FIND", "0") == "1"
     H, W, V, D = CONFIGS[args.config]
     h, w, C = H // 4, W // 4, 32
-    model, sd = build_mvsnet(D, dev)
+    half = args.config in HALF_FEATURES and not args.fp32
+    model, sd = build_mvsnet(D, dev, half_features=half)
     # this rank's frames: frame index = rank + world * i (round-robin shard of the frame list)
     nframes = 2
     from robustmvd_amd.sharding import frames_for_rank
@@ -196,7 +203,8 @@ def main():
 
     dt = timed_loop(model, samples, args.steps, args.warmup, world, dev, arm, cdev)
     k3_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    k3_bytes = 4.0 * ((V + 1) * C * h * w + C * D * h * w)  # SURVEY.md 8(d), batch 1 per launch
+    # SURVEY.md 8(d), batch 1 per launch; the fp16-feature variant moves 2-byte features and a 2-byte volume
+    k3_bytes = (2.0 if half else 4.0) * ((V + 1) * C * h * w + C * D * h * w)
     value = world * args.steps / dt
 
     out = {
@@ -204,7 +212,8 @@ def main():
         "metric": f"depth-maps/sec at {H}x{W}x{V}srcx{D}planes; warp+aggregate HBM GB/s vs roofline",
         "value": value, "unit": "depth-maps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "settle_forwards": SETTLE_FORWARDS,
+        "dtype": "f16 features + volume, f32 arithmetic (fp16-MFMA first regulariser layer, f32 accumulate)" if half else "f32",
+        "data": "synthetic", "settle_forwards": SETTLE_FORWARDS,
         "config": {"workload": f"mvsnet (Path B) forward {H}x{W}, {V} source views, {D} planes, batch 1 per step "
                                f"(BASELINE.json configs[{args.config}])",
                    "parallelism": f"{world} independent replica(s), frames round-robin, no collectives"},
@@ -221,7 +230,7 @@ def main():
                 traffic_src = "rocprofv3 PMC-derived constant, not measured in this run: " + str(tj.get("source", tpath))
         copy_gbs = measured_copy_gbs(dev)
         achieved = k3_bytes / (k3_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "warp_variance (K3)", "achieved": achieved,
+        out["roofline"] = {"bound": "hbm", "kernel": "warp_variance_f16 (K3)" if half else "warp_variance (K3)", "achieved": achieved,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": k3_bytes,
                            "avg_launch_ms": k3_ms, "launches_timed": args.steps, "measured_copy_peak_gbs": copy_gbs,

@@ -120,6 +120,22 @@ int mvd_warp_variance_f32(const float* key_feat, const float* const* src_feat, c
                           int V, float* var_out, int out_layout, void* workspace, size_t workspace_bytes,
                           mvd_stream_t stream);
 
+/* K3, fp16-feature variant (BASELINE.json configs[3]: "fp16 features"; SURVEY.md 8b names mvd_warp_variance_{f32,f16}).
+ * Same operation as mvd_warp_variance_f32 with MVD_FEAT_NHWC_BORDER | MVD_LAYOUT_NDHWC, C = 32:
+ *   key_feat, src_feat[v]   fp16 zero-bordered channel-last maps (B,h+3,w+3,32) (map at rows/cols 1..h / 1..w, zeros around)
+ *   var_out                 fp16 channel-last volume (B,D,h,w,32)
+ * Sampling positions, bilinear weights, the blend and the variance are computed in fp32 exactly as in the f32 entry point
+ * (the fp16 taps enter the same fmaf chain): the result equals the f32 kernel's on the same fp16-representable feature
+ * values, rounded once (to nearest even) to fp16 on the way out.  Calibration stays fp32.
+ * Algorithmic HBM bytes: 2*((V+1)*C*h*w + C*D*h*w)*B — the volume is stored fp16 (1,137.5 MB at configs[3]). */
+size_t mvd_warp_variance_f16_workspace_bytes(int B);
+int mvd_warp_variance_f16(const void* key_feat, const void* const* src_feat, const float* const* src_proj,
+                          const float* key_proj_inv, const float* depth_values, int B, int D, int h, int w, int V,
+                          void* var_out, void* workspace, size_t workspace_bytes, mvd_stream_t stream);
+/* elementwise fp32 <-> fp16 (round to nearest even); n must be a multiple of 4 */
+int mvd_convert_f32_to_f16(const float* src, void* dst, long long n, mvd_stream_t stream);
+int mvd_convert_f16_to_f32(const void* src, float* dst, long long n, mvd_stream_t stream);
+
 /* homo_warp alone (one view, no aggregation): rmvd/models/blocks/utils.py:222-268 -> (B,C,D,h,w). */
 int mvd_homo_warp_f32(const float* src_feat, const float* src_proj, const float* key_proj_inv,
                       const float* depth_values, int B, int C, int D, int h, int w, float* warped_out,
@@ -142,6 +158,17 @@ int mvd_pack_conv3d_weights_f32(const float* w, int Cin, int Cout, int mode, flo
 int mvd_conv3d_bn_relu_f32(const float* x, const float* packed_w, const float* scale, const float* shift,
                            const float* skip, float* y, int B, int Di, int hi, int wi, int Cin, int Cout, int mode,
                            int relu, mvd_stream_t stream);
+
+/* K4, fp16-input first layer (BASELINE.json configs[3]: "3D-conv regulariser on MFMA, fp16 features"): conv0 of
+ * CostRegNet (mvsnet_components.py:78; ConvBnReLU3D 32 -> 8, 3x3x3, stride 1, padding 1, :25-41) on
+ * v_mfma_f32_16x16x32_f16 — fp16 operands (the volume of mvd_warp_variance_f16 and the weights rounded to fp16),
+ * fp32 accumulation, fp32 BN scale/shift + ReLU epilogue, fp32 output that feeds mvd_conv3d_bn_relu_f32 layers.
+ *   x (B,D,h,w,32) fp16 channel-last -> y (B,D,h,w,8) fp32 channel-last.  Only Cin = 32, Cout = 8 is built. */
+size_t mvd_conv3d_f16_packed_weight_bytes(int Cin, int Cout);
+/* w: Conv3d layout (Cout,Cin,3,3,3) fp32; rounded to fp16 and laid out in MFMA fragment order */
+int mvd_pack_conv3d_weights_f16(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream);
+int mvd_conv3d_bn_relu_f16in(const void* x, const void* packed_w, const float* scale, const float* shift, float* y, int B,
+                             int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
 
 /* K6 — one layer of MVSNet's FeatureNet (rmvd/models/blocks/mvsnet_components.py:44-66; ConvBnReLU :8-22) as an
  * implicit GEMM on the fp32 matrix cores: Conv2d k x k with padding k/2 (k = 3 stride 1, or k = 5 stride 2), then a

@@ -42,10 +42,19 @@ SIGNATURES = {
     "mvd_warp_variance_workspace_bytes": (_sz, [_i] * 5),
     "mvd_warp_variance_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p] + [_i] * 6
                               + [_c_float_p, _i, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_warp_variance_f16_workspace_bytes": (_sz, [_i]),
+    "mvd_warp_variance_f16": (_i, [ctypes.c_void_p, _pp, _pp, _c_float_p, _c_float_p] + [_i] * 5
+                              + [ctypes.c_void_p, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_convert_f32_to_f16": (_i, [_c_float_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]),
+    "mvd_convert_f16_to_f32": (_i, [ctypes.c_void_p, _c_float_p, ctypes.c_longlong, ctypes.c_void_p]),
     "mvd_homo_warp_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [_c_float_p, ctypes.c_void_p, _sz, ctypes.c_void_p]),
     "mvd_conv3d_packed_weight_floats": (_sz, [_i, _i]),
     "mvd_pack_conv3d_weights_f32": (_i, [_c_float_p, _i, _i, _i, _c_float_p, ctypes.c_void_p]),
     "mvd_conv3d_bn_relu_f32": (_i, [_c_float_p] * 6 + [_i] * 8 + [ctypes.c_void_p]),
+    "mvd_conv3d_f16_packed_weight_bytes": (_sz, [_i, _i]),
+    "mvd_pack_conv3d_weights_f16": (_i, [_c_float_p, _i, _i, ctypes.c_void_p, ctypes.c_void_p]),
+    "mvd_conv3d_bn_relu_f16in": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7
+                                 + [ctypes.c_void_p]),
     "mvd_conv2d_packed_weight_floats": (_sz, [_i, _i, _i]),
     "mvd_pack_conv2d_weights_f32": (_i, [_c_float_p, _i, _i, _i, _c_float_p, ctypes.c_void_p]),
     "mvd_conv2d_bn_relu_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _i] + [_i] * 8
@@ -124,6 +133,21 @@ def ptr(t):
 def ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return ctypes.cast(arr, _pp), arr  # keep `arr` alive in the caller
+
+
+def as_f16(t, name, shape=None, device=None):
+    """Like as_f32 for the fp16 entry points: no silent conversion, the caller decides where the rounding happens."""
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: tensor is on {t.device}; the HIP engine needs a cuda (ROCm) device tensor")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name}: on {t.device}, expected {device}")
+    if t.dtype != torch.float16:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected torch.float16")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t.contiguous()
 
 
 def as_f32(t, name, shape=None, device=None):

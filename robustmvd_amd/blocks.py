@@ -237,12 +237,15 @@ class CostRegNet(nn.Module):
             pk[name] = (w, cin, cout, *fold_bn(m[1]), L.DECONV3D_STRIDE2)
         w, _, _ = ops.pack_conv3d_weights(self.prob.weight.detach(), L.CONV3D_STRIDE1)
         pk["prob"] = (w, 8, 1, torch.ones(1, device=w.device), self.prob.bias.detach().contiguous(), L.CONV3D_STRIDE1)
+        # fp16-feature variant (BASELINE configs[3]): conv0's weights rounded to fp16 in fp16-MFMA fragment order
+        pk["conv0_f16"] = ops.pack_conv3d_weights_f16(self.conv0.conv.weight.detach())
         self._packed, self._packed_key = pk, key
         return pk
 
     @ops.inference_only
     def forward_channels_last(self, x):
-        """x (B,D,h,w,32) -> cost (B,D,h,w) (the single output channel squeezed)."""
+        """x (B,D,h,w,32) fp32, or fp16 (the fp16-feature variant: conv0 then runs on fp16 MFMA) -> cost (B,D,h,w) fp32
+        (the single output channel squeezed)."""
         if x.shape[1] % 8 or x.shape[2] % 8 or x.shape[3] % 8:
             raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {tuple(x.shape[1:4])}")
         pk = self._prepare()
@@ -251,7 +254,11 @@ class CostRegNet(nn.Module):
             w, cin, cout, scale, shift, mode = pk[name]
             return ops.conv3d_bn_relu(t, w, cin, cout, scale, shift, mode, relu=relu, skip=skip)
 
-        conv0 = layer("conv0", x)
+        if x.dtype == torch.float16:  # the fp16 volume of ops.warp_variance_f16: first layer on fp16 MFMA, fp32 out
+            _, _, _, scale0, shift0, _ = pk["conv0"]
+            conv0 = ops.conv3d_bn_relu_f16in(x, pk["conv0_f16"], scale0, shift0, relu=True)
+        else:
+            conv0 = layer("conv0", x)
         conv2 = layer("conv2", layer("conv1", conv0))
         conv4 = layer("conv4", layer("conv3", conv2))
         y = layer("conv6", layer("conv5", conv4))

@@ -464,8 +464,32 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
 // LDS (broadcast reads, no VALU) instead of computing and shuffling them, and keep at most three cells in flight
 // (gather_blend_4planes_lds) so that the kernel fits 128 VGPRs = 4 waves per SIMD.  Same arithmetic, operation for
 // operation, as warp_variance_kernel: results are bit-identical.
-template <int MASK, int I>
-__device__ __forceinline__ void blend_plane_lds(float4 (&s1)[4], float4 (&s2)[4], const float4 wq, const u32x4 (&f)[4]) {
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// by VALUE on purpose: __builtin_bit_cast applied directly to a vector component (t.y) reads the vector's first dword
+__device__ __forceinline__ f16x2 as_h2(unsigned v) { return __builtin_bit_cast(f16x2, v); }
+__device__ __forceinline__ unsigned as_u32(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+// fp16 taps (4 channels = 8 bytes per lane), fp32 weights and accumulation: fmaf((float)half, w, acc) is one
+// v_fma_mix_f32 (exact f16 -> f32 conversion inside the FMA), so the result equals the fp32 kernel's on the same
+// (fp16-representable) feature values, operation for operation
+__device__ __forceinline__ void accumulate_cell(float4& a1, float4& a2, const float (&w)[4], const u32x2 (&t)[4]) {
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f16x2 lo = as_h2(t[k].x), hi = as_h2(t[k].y);
+        acc.x = fmaf((float)lo.x, w[k], acc.x);
+        acc.y = fmaf((float)lo.y, w[k], acc.y);
+        acc.z = fmaf((float)hi.x, w[k], acc.z);
+        acc.w = fmaf((float)hi.y, w[k], acc.w);
+    }
+    a1.x += acc.x; a1.y += acc.y; a1.z += acc.z; a1.w += acc.w;
+    a2.x = fmaf(acc.x, acc.x, a2.x); a2.y = fmaf(acc.y, acc.y, a2.y);
+    a2.z = fmaf(acc.z, acc.z, a2.z); a2.w = fmaf(acc.w, acc.w, a2.w);
+}
+
+template <int MASK, int I, class TAP>
+__device__ __forceinline__ void blend_plane_lds(float4 (&s1)[4], float4 (&s2)[4], const float4 wq, const TAP (&f)[4]) {
     const float w[4] = {wq.x, wq.y, wq.z, wq.w};
     accumulate_cell(s1[I], s2[I], w, f);
 }
@@ -477,6 +501,24 @@ __device__ __forceinline__ void gather_cell_s(u32x4 (&f)[4], __amdgpu_buffer_rsr
     f[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 128u, 0, 0);
     f[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, rowb, 0);
     f[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 128u, rowb, 0);
+}
+// fp16 features: 64 bytes per pixel, 8 per lane
+// (the b64 builtins traffic in GCC-style vectors; an implicit conversion to an ext_vector_type silently narrows the load
+// to one dword with this compiler, so the lanes are moved explicitly)
+typedef unsigned int u32x2n __attribute__((vector_size(8)));
+__device__ __forceinline__ u32x2 load_b64(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u32x2n r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+    return u32x2{r[0], r[1]};
+}
+__device__ __forceinline__ void store_b64(u32x2 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    const u32x2n r = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(r, rsrc, voff, 0, 0);
+}
+__device__ __forceinline__ void gather_cell_s(u32x2 (&f)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned o, unsigned rowb) {
+    f[0] = load_b64(rsrc, o, 0);
+    f[1] = load_b64(rsrc, o + 64u, 0);
+    f[2] = load_b64(rsrc, o, rowb);
+    f[3] = load_b64(rsrc, o + 64u, rowb);
 }
 
 template <int MASK, int KO = 0>
@@ -657,14 +699,14 @@ constexpr int first_plane_of_cell(int mask, int k) {
     return 3;
 }
 
-template <int MASK, int K, int I>
-__device__ __forceinline__ void blend_if_cell(float4 (&s1)[4], float4 (&s2)[4], const float4 (&w)[4], const u32x4 (&X)[4],
-                                              const u32x4 (&Y)[4]) {
+template <int MASK, int K, int I, class TAP>
+__device__ __forceinline__ void blend_if_cell(float4 (&s1)[4], float4 (&s2)[4], const float4 (&w)[4], const TAP (&X)[4],
+                                              const TAP (&Y)[4]) {
     if constexpr (cell_of(MASK, I) == K) blend_plane_lds<MASK, I>(s1, s2, w[I], (K & 1) ? Y : X);
 }
 
-template <int MASK, int K>
-__device__ __forceinline__ void cell_step(float4 (&s1)[4], float4 (&s2)[4], const float4 (&w)[4], u32x4 (&X)[4], u32x4 (&Y)[4],
+template <int MASK, int K, class TAP>
+__device__ __forceinline__ void cell_step(float4 (&s1)[4], float4 (&s2)[4], const float4 (&w)[4], TAP (&X)[4], TAP (&Y)[4],
                                           const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb) {
     if constexpr (K < ncells_of(MASK)) {
         blend_if_cell<MASK, K, 0>(s1, s2, w, X, Y);
@@ -678,10 +720,10 @@ __device__ __forceinline__ void cell_step(float4 (&s1)[4], float4 (&s2)[4], cons
     }
 }
 
-template <int MASK>
+template <int MASK, class TAP = u32x4>
 __device__ __forceinline__ void gather_blend_4planes_2sets(float4 (&s1)[4], float4 (&s2)[4], const float4* __restrict__ wl,
                                                            const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb) {
-    u32x4 X[4], Y[4];
+    TAP X[4], Y[4];
     gather_cell_s(X, rsrc, off[0], rowb);
     if constexpr (ncells_of(MASK) > 1) gather_cell_s(Y, rsrc, off[first_plane_of_cell(MASK, 1)], rowb);
     const float4 w[4] = {wl[0], wl[32], wl[64], wl[96]};
@@ -691,10 +733,13 @@ __device__ __forceinline__ void gather_blend_4planes_2sets(float4 (&s1)[4], floa
     cell_step<MASK, 3>(s1, s2, w, X, Y, off, rsrc, rowb);
 }
 
-template <int MINW, int NSETS>
+// F16: features are fp16 zero-bordered channel-last maps (64 B per pixel), the volume is written as fp16 (B,D,h,w,32);
+// positions, weights, blend and variance stay fp32 (mvd_warp_variance_f16, BASELINE configs[3]).
+template <int MINW, int NSETS, bool F16 = false>
 __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpParams p, int nch) {
     constexpr int DPB = 4, PPB = 32;
-    constexpr unsigned PIX = 128;
+    constexpr unsigned PIX = F16 ? 64 : 128;  // bytes per pixel
+    constexpr unsigned QB = F16 ? 8 : 16;     // bytes per lane (4 channels)
     extern __shared__ __attribute__((aligned(16))) float4 lds_raw[];  // 2 x ([V][4][32] float4 weights + [V][4][32] u32 offsets)
     const int V = p.V;
     const int half_q = V * (DPB * PPB) * 5 / 4;  // float4 slots per table half (weights + offsets)
@@ -763,17 +808,25 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
     // blend-phase constants: 8 lanes per pixel, 4 channels per lane
     const int q = tid & 7, px = tid >> 3;
     const int xc = min(x0 + px, w - 1);
-    const unsigned org = rowb + PIX + (unsigned)q * 16;  // padded (1,1) + this lane's channel quad
+    const unsigned org = rowb + PIX + (unsigned)q * QB;  // padded (1,1) + this lane's channel quad
     // the key features of this thread's (pixel, channel quad) stay in LDS between chunks (4 fewer long-lived VGPRs)
     float4* __restrict__ key_slot = lds_raw + 2 * half_q + tid;
-    *key_slot = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.key) + (size_t)b * img_bytes + org +
-                                                 (unsigned)y * rowb + (unsigned)xc * PIX);
+    {
+        const char* kp = reinterpret_cast<const char*>(p.key) + (size_t)b * img_bytes + org + (unsigned)y * rowb + (unsigned)xc * PIX;
+        if constexpr (F16) {
+            const u32x2 kh = *reinterpret_cast<const u32x2*>(kp);
+            const f16x2 lo = as_h2(kh.x), hi = as_h2(kh.y);
+            *key_slot = make_float4((float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y);
+        } else {
+            *key_slot = *reinterpret_cast<const float4*>(kp);
+        }
+    }
     const float inv_nv = 1.0f / (float)(V + 1);  // mvsnet.py:135, V there counts the key view
     // stores: one descriptor per output plane (scalar arithmetic), one 32-bit offset per lane.  Inactive lanes (ragged
     // right edge) carry pixel w-1 like the last active lane and store the same values to the same address: no divergent
     // branch around the stores
-    const unsigned out_off = ((unsigned)y * (unsigned)w + (unsigned)xc) * 128u + (unsigned)q * 16u;
-    const size_t plane_bytes = (size_t)h * w * 128;
+    const unsigned out_off = ((unsigned)y * (unsigned)w + (unsigned)xc) * PIX + (unsigned)q * QB;
+    const size_t plane_bytes = (size_t)h * w * PIX;
 
     locate(c_begin, 0);
     int buf = 0;
@@ -809,9 +862,10 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
             const unsigned mask = (__builtin_amdgcn_ballot_w64(off[1] != off[0]) != 0 ? 1u : 0u) |
                                   (__builtin_amdgcn_ballot_w64(off[2] != off[1]) != 0 ? 2u : 0u) |
                                   (__builtin_amdgcn_ballot_w64(off[3] != off[2]) != 0 ? 4u : 0u);
-#define MVD_CASE(Mk)                                                                         \
-    if constexpr (NSETS == 2) gather_blend_4planes_2sets<Mk>(s1, s2, wl, off, rsrc, rowb); \
-    else gather_blend_4planes_lds<Mk>(s1, s2, wl, off, rsrc, rowb);                         \
+#define MVD_CASE(Mk)                                                                                   \
+    if constexpr (F16) gather_blend_4planes_2sets<Mk, u32x2>(s1, s2, wl, off, rsrc, rowb);             \
+    else if constexpr (NSETS == 2) gather_blend_4planes_2sets<Mk, u32x4>(s1, s2, wl, off, rsrc, rowb); \
+    else gather_blend_4planes_lds<Mk>(s1, s2, wl, off, rsrc, rowb);                                   \
     break;
             switch (mask) {
                 case 0: MVD_CASE(0)
@@ -834,20 +888,25 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
                                          fmaf(s2[i].z, inv_nv, -mz * mz), fmaf(s2[i].w, inv_nv, -mw * mw));
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
                 reinterpret_cast<char*>(p.out) + ((size_t)b * D + d0 + i) * plane_bytes, 0, (int)plane_bytes, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z),
-                                                         __float_as_uint(r.w)}, orsrc, out_off, 0, 0);
+            if constexpr (F16) {  // round to nearest even, one rounding
+                const f16x2 lo = {(_Float16)r.x, (_Float16)r.y}, hi = {(_Float16)r.z, (_Float16)r.w};
+                store_b64(u32x2{as_u32(lo), as_u32(hi)}, orsrc, out_off);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z),
+                                                             __float_as_uint(r.w)}, orsrc, out_off, 0, 0);
+            }
         }
     }
 }
 
-static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int nsets, int nch) {
+static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int nsets, int nch, bool f16 = false) {
     WarpParams p = p0;
     p.tiles_x = (p.w + 31) / 32;
     const long long tiles = (long long)p.tiles_x * p.h;
     p.tiles_per_xcd = (int)((tiles + 7) / 8);
     const int dchunks = (p.D + 3) / 4;
     if (nch < 1) nch = 1;
-    if ((long long)p.h * p.w * 128 >= 0x7fffffffLL) {  // one output plane is addressed through a 32-bit buffer offset
+    if ((long long)p.h * p.w * (f16 ? 64 : 128) >= 0x7fffffffLL) {  // one output plane is addressed through a 32-bit buffer offset
         set_error("warp_variance: an output plane of %dx%dx32 floats exceeds the 2 GiB buffer-offset range", p.h, p.w);
         return MVD_ERR_INVALID_ARG;
     }
@@ -861,6 +920,11 @@ static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int
     const dim3 grid((unsigned)nblk);
     timing_begin(st);
 #define MVD_M(MW, NS) hipLaunchKernelGGL((warp_variance_march_kernel<MW, NS>), grid, dim3(256), lds, st, p, nch)
+    if (f16) {
+        hipLaunchKernelGGL((warp_variance_march_kernel<4, 2, true>), grid, dim3(256), lds, st, p, nch);
+        timing_end(st);
+        return launch_status("warp_variance_march_f16");
+    }
     switch (minw * 10 + nsets) {
 #ifdef MVD_EXPERIMENTS
         case 43: MVD_M(4, 3); break;
@@ -1102,9 +1166,87 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
     return warp_only ? launch_warp<true>(p, C, st) : launch_warp<false>(p, C, st);
 }
 
+// fp16-feature variant (BASELINE configs[3]): features arrive as fp16 zero-bordered channel-last maps, the volume
+// leaves as fp16 channel-last; everything in between is the fp32 arithmetic of the marching kernel
+static int run_warp_f16(const void* key_feat, const void* const* src_feat, const float* const* src_proj,
+                        const float* key_proj_inv, const float* depth_values, int B, int D, int h, int w, int V, void* out,
+                        void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const char* who = "warp_variance_f16";
+    MVD_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "%s: non-positive dimension (h, w must be >= 2)", who);
+    MVD_REQUIRE(V >= 1 && V <= MVD_MAX_VIEWS, "%s: V=%d outside 1..%d", who, V, MVD_MAX_VIEWS);
+    MVD_REQUIRE((long long)(h + 3) * (w + 3) * 64 < 0x7fffffffLL && h < (1 << 23) && w < (1 << 23),
+                "%s: one padded feature map of %dx%dx32 halves exceeds the 2 GiB buffer-offset range", who, h, w);
+    const size_t need = align_up((size_t)MVD_MAX_VIEWS * B * 12 * sizeof(float), 256);
+    if (!workspace || workspace_bytes < need) {
+        set_error("%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
+        return MVD_ERR_WORKSPACE;
+    }
+    WarpParams p{};
+    p.M = (float*)workspace;
+    p.key = (const float*)key_feat;
+    for (int v = 0; v < V; ++v) {
+        MVD_REQUIRE(src_feat[v] && src_proj[v], "%s: NULL view %d", who, v);
+        p.src.p[v] = (const float*)src_feat[v];
+        p.proj.p[v] = src_proj[v];
+    }
+    hipLaunchKernelGGL(compose_transforms_kernel, dim3((unsigned)((V * B * 12 + 255) / 256)), dim3(256), 0, st, p.proj,
+                       key_proj_inv, B, V, const_cast<float*>(p.M));
+    int rc = launch_status("compose_transforms");
+    if (rc) return rc;
+    p.key_proj_inv = key_proj_inv;
+    p.depth = depth_values;
+    p.out = (float*)out;
+    p.B = B; p.D = D; p.h = h; p.w = w; p.V = V;
+    p.layout = MVD_LAYOUT_NDHWC;
+    return launch_warp_march(p, st, 4, 2, 4, true);
+}
+
+template <bool TO_HALF>
+__global__ void __launch_bounds__(256) convert_kernel(const void* __restrict__ src, void* __restrict__ dst, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // 4 elements per thread
+    if (i >= n4) return;
+    if constexpr (TO_HALF) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        const f16x2 lo = {(_Float16)v.x, (_Float16)v.y}, hi = {(_Float16)v.z, (_Float16)v.w};
+        reinterpret_cast<u32x2*>(dst)[i] = u32x2{as_u32(lo), as_u32(hi)};
+    } else {
+        const u32x2 v = reinterpret_cast<const u32x2*>(src)[i];
+        const f16x2 lo = as_h2(v.x), hi = as_h2(v.y);
+        reinterpret_cast<float4*>(dst)[i] = make_float4((float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y);
+    }
+}
+
+template <bool TO_HALF>
+static int convert(const void* src, void* dst, long long n, hipStream_t st) {
+    MVD_REQUIRE(src && dst && n > 0 && n % 4 == 0, "convert: NULL argument or element count not a positive multiple of 4");
+    const long long n4 = n / 4, nblk = (n4 + 255) / 256;
+    MVD_REQUIRE(nblk <= 0x7fffffffLL, "convert: too many elements");
+    hipLaunchKernelGGL(convert_kernel<TO_HALF>, dim3((unsigned)nblk), dim3(256), 0, st, src, dst, n4);
+    return launch_status("convert");
+}
+
 }  // namespace mvd
 
 extern "C" {
+
+size_t mvd_warp_variance_f16_workspace_bytes(int B) {
+    return B > 0 ? mvd::align_up((size_t)MVD_MAX_VIEWS * B * 12 * sizeof(float), 256) : 0;
+}
+
+int mvd_warp_variance_f16(const void* key_feat, const void* const* src_feat, const float* const* src_proj,
+                          const float* key_proj_inv, const float* depth_values, int B, int D, int h, int w, int V,
+                          void* var_out, void* workspace, size_t workspace_bytes, mvd_stream_t stream) {
+    MVD_REQUIRE(key_feat && src_feat && src_proj && key_proj_inv && depth_values && var_out, "warp_variance_f16: NULL argument");
+    return mvd::run_warp_f16(key_feat, src_feat, src_proj, key_proj_inv, depth_values, B, D, h, w, V, var_out, workspace,
+                             workspace_bytes, (hipStream_t)stream);
+}
+
+int mvd_convert_f32_to_f16(const float* src, void* dst, long long n, mvd_stream_t stream) {
+    return mvd::convert<true>(src, dst, n, (hipStream_t)stream);
+}
+int mvd_convert_f16_to_f32(const void* src, float* dst, long long n, mvd_stream_t stream) {
+    return mvd::convert<false>(src, dst, n, (hipStream_t)stream);
+}
 
 size_t mvd_warp_variance_workspace_bytes(int B, int C, int h, int w, int V) {
     if (B <= 0 || C <= 0 || h <= 0 || w <= 0 || V < 0) return 0;

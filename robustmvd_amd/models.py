@@ -130,8 +130,13 @@ class RobustMVD(nn.Module):
 
 
 class MVSNet(nn.Module):
-    def __init__(self, sample_in_inv_depth_space=False, num_sampling_steps=192):
+    def __init__(self, sample_in_inv_depth_space=False, num_sampling_steps=192, half_features=False):
+        """half_features (an extension; the reference has no such switch): BASELINE.json configs[3] — the feature maps
+        are rounded to fp16 before the sweep, the variance volume is stored fp16 and the regulariser's first layer runs
+        on fp16 MFMA with fp32 accumulation; everything else (positions, blend, variance, layers 2..11, soft argmin)
+        stays fp32.  Regressed depth within rtol 1e-2 of the fp32 path."""
         super().__init__()
+        self.half_features = bool(half_features)
         if sample_in_inv_depth_space:
             raise NotImplementedError("sample_in_inv_depth_space=True is a dead branch in the reference "
                                       "(tensor[::-1] raises, mvsnet.py:50,56-63)")
@@ -200,8 +205,13 @@ class MVSNet(nn.Module):
 
         # K6 x 8: ((V+1)*B, h+3, w+3, 32), the last layer writing straight into K3's zero-bordered staging layout
         feats = self.feature.forward_layout(torch.cat(views, 0), L.LAYOUT_NHWC_BORDER)
+        if self.half_features:
+            feats = ops.to_f16(feats)  # one rounding to fp16 (zero border stays zero)
         feats = list(torch.split(feats, n, 0))
-        var = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True, staged=True)  # K3
+        if self.half_features:
+            var = ops.warp_variance_f16(feats[0], feats[1:], projs[1:], projs[0], depth_samples)                          # K3 (fp16)
+        else:
+            var = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True, staged=True)  # K3
         cost = self.cost_regularization.forward_channels_last(var)                                              # K4
         del var
         depth, conf = ops.softmax_regress(cost, depth_samples)                                                  # K5

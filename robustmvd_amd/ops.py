@@ -154,6 +154,48 @@ def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, ch
 
 
 @inference_only
+def to_f16(x):
+    """fp32 -> fp16 (round to nearest even) through the library's converter; numel must be a multiple of 4."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mvd_convert_f32_to_f16(L.ptr(x), L.ptr(y), x.numel(), L.stream_of(x))
+    L.check(rc, "mvd_convert_f32_to_f16")
+    return y
+
+
+@inference_only
+def warp_variance_f16(key_feat, src_feats, src_projs, key_proj_inv, depth_values):
+    """K3, fp16-feature variant (mvd_warp_variance_f16).  key_feat, src_feats: fp16 zero-bordered channel-last maps
+    (B,h+3,w+3,32); calibration fp32.  Returns the fp16 channel-last variance volume (B,D,h,w,32)."""
+    lib = L.load()
+    kf = L.as_f16(key_feat, "key_feat")
+    if kf.dim() != 4 or kf.shape[3] != 32:
+        raise ValueError("key_feat must be the fp16 zero-bordered channel-last map (B,h+3,w+3,32)")
+    B, h, w = kf.shape[0], kf.shape[1] - 3, kf.shape[2] - 3
+    dev = kf.device
+    srcs = [L.as_f16(s, f"src_feats[{i}]", tuple(kf.shape), dev) for i, s in enumerate(_views(src_feats, "src_feats"))]
+    V = len(srcs)
+    projs = [L.as_f32(p, f"src_projs[{i}]", (B, 4, 4), dev) for i, p in enumerate(_views(src_projs, "src_projs", V))]
+    kpi = L.as_f32(key_proj_inv, "key_proj_inv", (B, 4, 4), dev)
+    dv = L.as_f32(depth_values, "depth_values", device=dev)
+    if dv.dim() != 2 or dv.shape[0] != B:
+        raise ValueError(f"depth_values must be (B,D), got {tuple(dv.shape)}")
+    D = dv.shape[1]
+    out = torch.empty((B, D, h, w, 32), dtype=torch.float16, device=dev)
+    wsb = lib.mvd_warp_variance_f16_workspace_bytes(B)
+    wsp = _workspace(wsb, dev)
+    a_s, k1 = L.ptr_array(srcs)
+    a_p, k2 = L.ptr_array(projs)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_warp_variance_f16(L.ptr(kf), a_s, a_p, L.ptr(kpi), L.ptr(dv), B, D, h, w, V, L.ptr(out), L.ptr(wsp), wsb,
+                                       L.stream_of(kf))
+    L.check(rc, "mvd_warp_variance_f16")
+    return out
+
+
+@inference_only
 def homo_warp(src_feat, src_proj, ref_proj_inv, depth_values):
     """Drop-in for rmvd.models.blocks.utils.homo_warp (blocks/utils.py:222): -> (B,C,D,H,W)."""
     lib = L.load()
@@ -229,6 +271,39 @@ def conv3d_bn_relu(x, packed, Cin, Cout, scale, shift, mode, relu=True, skip=Non
         rc = lib.mvd_conv3d_bn_relu_f32(L.ptr(x), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(skip), L.ptr(y), B, Di,
                                         hi, wi, Cin, Cout, mode, int(bool(relu)), L.stream_of(x))
     L.check(rc, "mvd_conv3d_bn_relu_f32")
+    return y
+
+
+@inference_only
+def pack_conv3d_weights_f16(weight):
+    """weight: Conv3d (8,32,3,3,3) fp32 -> fp16 MFMA-fragment-ordered buffer for conv3d_bn_relu_f16in."""
+    lib = L.load()
+    wt = L.as_f32(weight, "weight")
+    if tuple(wt.shape) != (8, 32, 3, 3, 3):
+        raise ValueError(f"conv3d f16: only the 32 -> 8 first layer is built, got weight {tuple(wt.shape)}")
+    packed = torch.empty(lib.mvd_conv3d_f16_packed_weight_bytes(32, 8), dtype=torch.uint8, device=wt.device)
+    with torch.cuda.device(wt.device):
+        rc = lib.mvd_pack_conv3d_weights_f16(L.ptr(wt), 32, 8, L.ptr(packed), L.stream_of(wt))
+    L.check(rc, "mvd_pack_conv3d_weights_f16")
+    return packed
+
+
+@inference_only
+def conv3d_bn_relu_f16in(x, packed, scale, shift, relu=True):
+    """K4 first layer on fp16 MFMA: x (B,D,h,w,32) fp16 channel-last -> (B,D,h,w,8) fp32."""
+    lib = L.load()
+    x = L.as_f16(x, "x")
+    if x.dim() != 5 or x.shape[-1] != 32:
+        raise ValueError(f"x must be (B,D,h,w,32) fp16 channel-last, got {tuple(x.shape)}")
+    B, D, h, w, _ = x.shape
+    dev = x.device
+    scale = L.as_f32(scale, "scale", (8,), dev)
+    shift = L.as_f32(shift, "shift", (8,), dev)
+    y = torch.empty((B, D, h, w, 8), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_conv3d_bn_relu_f16in(L.ptr(x), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), B, D, h, w, 32, 8,
+                                          int(bool(relu)), L.stream_of(x))
+    L.check(rc, "mvd_conv3d_bn_relu_f16in")
     return y
 
 

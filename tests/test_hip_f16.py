@@ -1,0 +1,116 @@
+"""GPU parity of the fp16-feature variant (BASELINE.json configs[3]: 896x1216, 4 source views, 256 planes, "3D-conv
+regulariser on MFMA, fp16 features"; SURVEY.md 8b `mvd_warp_variance_{f32,f16}`).
+
+What is fp16: the feature maps handed to the sweep (one rounding), the stored variance volume (one rounding), and the
+operands of the regulariser's first layer (fp16 MFMA, fp32 accumulation).  Everything else is the fp32 path.
+  * K3-f16 against the fp32 kernel / the CPU oracle fed the SAME fp16-representable features: identical arithmetic, so the
+    only difference is the final rounding of the volume to fp16 (rel 2^-11);
+  * conv0-f16 against the C oracle's conv3d on the fp16-rounded input and weights: fp32 accumulation order differs
+    (one K=32 MFMA per tap) -> atol/rtol 1e-3;
+  * the whole MVSNet forward with half_features=True against the fp32 CPU oracle pipeline at configs[3]'s full size:
+    regressed depth rtol 1e-2.
+"""
+import numpy as np
+import pytest
+import torch
+
+import gen_common as gc
+from oracle import c_oracle as CO
+from oracle import pipeline as PL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def bordered(f, dev, dtype):
+    """(B,C,h,w) numpy -> zero-bordered channel-last (B,h+3,w+3,C) device tensor"""
+    B, C, h, w = f.shape
+    out = torch.zeros((B, h + 3, w + 3, C), dtype=dtype, device=dev)
+    out[:, 1:h + 1, 1:w + 1] = T(f, dev).permute(0, 2, 3, 1).to(dtype)
+    return out
+
+
+@pytest.mark.parametrize("B,h,w,D,V", [(1, 24, 40, 8, 2), (2, 37, 53, 5, 3), (1, 9, 70, 7, 6), (1, 64, 96, 16, 4)])
+def test_warp_variance_f16_equals_f32_kernel_on_fp16_features(B, h, w, D, V, dev):
+    from robustmvd_amd import ops
+    from test_hip_shapes import mvs_inputs
+    feats, projs, key_inv, depth = mvs_inputs(B, 32, h, w, D, V, seed=h * 7 + V)
+    feats = [f.astype(np.float16).astype(np.float32) for f in feats]  # fp16-representable values
+    args = ([T(p, dev) for p in projs], T(key_inv, dev), T(depth, dev))
+    f32 = [bordered(f, dev, torch.float32) for f in feats]
+    f16 = [bordered(f, dev, torch.float16) for f in feats]
+    want = ops.warp_variance(f32[0], f32[1:], *args, channels_last=True, staged=True)
+    got = ops.warp_variance_f16(f16[0], f16[1:], *args)
+    assert got.dtype == torch.float16 and tuple(got.shape) == (B, D, h, w, 32)
+    assert torch.equal(got, want.half())  # same fp32 arithmetic, one rounding at the end
+    ref = CO.warp_variance(feats[0], feats[1:], projs, key_inv, depth)
+    np.testing.assert_allclose(got.float().permute(0, 4, 1, 2, 3).cpu().numpy(), ref, atol=2e-3, rtol=2e-3)
+    with pytest.raises(ValueError, match="float16"):
+        ops.warp_variance_f16(f32[0], f32[1:], *args)
+
+
+def test_convert_roundtrip(dev):
+    from robustmvd_amd import ops
+    x = torch.randn(3, 5, 8, device=dev) * 100
+    assert torch.equal(ops.to_f16(x), x.half())
+
+
+@pytest.mark.parametrize("D,h,w", [(5, 7, 50), (9, 12, 130), (33, 6, 64), (4, 17, 16)])
+def test_conv0_f16_vs_oracle(D, h, w, dev):
+    from robustmvd_amd import ops
+    rng = np.random.default_rng(D * 100 + w)
+    x = rng.standard_normal((32, D, h, w)).astype(np.float16)
+    wt = (rng.standard_normal((8, 32, 3, 3, 3)) * np.sqrt(2 / (32 * 27))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 8).astype(np.float32)
+    shift = (rng.standard_normal(8) * 0.1).astype(np.float32)
+    ref = CO.conv3d(x.astype(np.float32), wt.astype(np.float16).astype(np.float32), scale, shift, stride=1, relu=True)
+    xt = T(x, dev).permute(1, 2, 3, 0).contiguous()[None]
+    got = ops.conv3d_bn_relu_f16in(xt, ops.pack_conv3d_weights_f16(T(wt, dev)), T(scale, dev), T(shift, dev))
+    assert got.dtype == torch.float32 and tuple(got.shape) == (1, D, h, w, 8)
+    np.testing.assert_allclose(got[0].permute(3, 0, 1, 2).cpu().numpy(), ref, atol=1e-3, rtol=1e-3)
+
+
+def _half_model(D, seed, dev):
+    import robustmvd_amd as R
+    model = R.MVSNet(num_sampling_steps=D, half_features=True).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.fill_state_dict(shapes, seed)
+    full = model.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    return R.add_run_function(model.to(dev)), sd
+
+
+def _check_against_fp32_oracle(H, W, V, D, seed, dev):
+    model, sd = _half_model(D, seed, dev)
+    s = gc.synthetic_sample(seed, H, W, V)
+    pred, _ = model.run(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0,
+                        depth_range=(np.float32(0.5), np.float32(10.0)))
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
+    images = [((im / 255.0 - mean) / std).astype(np.float32)[None] for im in s["images"]]
+    ref = PL.mvsnet_forward(images, [p[None] for p in s["poses"]], [k[None] for k in s["intrinsics"]], 0, (0.5, 10.0), sd, D)
+    np.testing.assert_allclose(pred["depth"], ref["depth"][0], rtol=1e-2)  # fp16-feature config
+    return pred, ref
+
+
+def test_mvsnet_half_features_small_vs_fp32_oracle(dev):
+    _check_against_fp32_oracle(64, 96, 2, 16, 21, dev)
+
+
+def test_mvsnet_half_features_at_config3_vs_fp32_oracle(dev):
+    """BASELINE configs[3] as named: 896x1216, 4 source views, 256 planes -> 224x304x256 volume, fp16 features."""
+    pred, ref = _check_against_fp32_oracle(896, 1216, 4, 256, 103, dev)
+    assert pred["depth"].shape == (1, 224, 304)
+    rel = np.abs(pred["depth"] - ref["depth"][0]) / ref["depth"][0]
+    print(f"configs[3] half_features: max rel depth error {rel.max():.2e}, median {np.median(rel):.2e}")
