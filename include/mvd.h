@@ -209,6 +209,34 @@ int mvd_arm_kernel_timing(void* start_event, void* stop_event);
  * The convolutions themselves stay on the vendor library; this replaces the two elementwise passes after each. */
 int mvd_bias_leaky_relu_f32(float* x, const float* bias, int N, int C, long long HW, float slope, mvd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the sweep operators w.r.t. the feature maps, for the training loop
+ * (rmvd/train/multi_view_depth_training.py:231-246).  The sampling grids carry no gradient (planesweep_corr.py:436,464,489;
+ * homo_warp's grid depends on calibration only).  Scatter-adds use float atomics: run-to-run summation order varies.
+ * All feature / gradient maps are CHANNEL-LAST; source maps are zero-bordered (.., h+3, w+3, C) with the map at (1,1), as in
+ * the forward kernels.  The callee zeroes the gradient outputs it accumulates into.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* VJP of mvd_warp_variance_f32.  key_feat, src_feat[v], grad_key, grad_src[v]: (B,h+3,w+3,C) zero-bordered channel-last
+ * (gradient border entries = the share of taps that fell on the zero padding; discard them); grad_var (B,D,h,w,C). */
+size_t mvd_warp_variance_backward_workspace_bytes(int B);
+int mvd_warp_variance_backward_f32(const float* key_feat, const float* const* src_feat, const float* const* src_proj,
+                                   const float* key_proj_inv, const float* depth_values, const float* grad_var, int B, int C,
+                                   int D, int h, int w, int V, float* grad_key, float* const* grad_src, void* workspace,
+                                   size_t workspace_bytes, mvd_stream_t stream);
+
+/* VJP of mvd_sweep_corr_f32 (masks are constants).  feat_key, grad_key (N,h,w,C) channel-last; feat_src[v], grad_src[v]
+ * (N,hs+3,ws+3,C) zero-bordered channel-last; grad_corr[v] (N,S,h,w).  C in {64,128,192,256}. */
+int mvd_sweep_corr_backward_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
+                                const float* const* K_src, const float* const* T_src2key, const float* invdepths,
+                                int invdepth_batched, const float* const* grad_corr, int N, int C, int h, int w, int hs, int ws,
+                                int S, int V, float* grad_key, float* const* grad_src, mvd_stream_t stream);
+
+/* VJP of mvd_fuse_views_f32 w.r.t. corr[v] (N,S,h,w) and score[v] (N,1,h,w); masks and the fused mask are constants. */
+int mvd_fuse_views_backward_f32(const float* const* corr, const float* const* mask, const float* const* score,
+                                const float* grad_fused, int N, int S, int h, int w, int V, float* const* grad_corr,
+                                float* const* grad_score, mvd_stream_t stream);
+
 /* Input resize of the model adapters: replaces ResizeInputs / UpscaleInputsToNextMultipleOf
  * (rmvd/data/transforms.py:40-98, called from robust_mvd.py:104-113 and mvsnet.py:178), i.e.
  * skimage.transform.resize(order=1) for UPSCALING (ho >= hi, wo >= wi): no anti-aliasing, float32 kept, mirror boundary,

@@ -422,3 +422,110 @@ def resize_inputs(images, intrinsics, ht, wd):
         scale = np.array([[wd / orig_wd] * 3, [ht / orig_ht] * 3, [1.0] * 3], dtype=np.float32)
         intrinsics = [k * scale for k in intrinsics]
     return images, intrinsics
+
+
+# =============================================================================================
+# Backward of the sweep ops w.r.t. the feature maps.  The sampling grids carry no gradient
+# (planesweep_corr.py:436,464,489 compute them under no_grad; homo_warp's grid depends on calibration only), so the
+# vector-Jacobian products are the transposes of the bilinear gathers.  Pinned against autograd through the imported
+# reference (tests/golden/g10_grads.npz, tests/test_oracle_golden.py).
+# =============================================================================================
+def grid_sample_zeros_backward(gout, ix, iy, hs, ws):
+    """Transpose of grid_sample_zeros: gout (C, *ix.shape) -> gradient w.r.t. img (C,hs,ws)."""
+    C = gout.shape[0]
+    gimg = np.zeros((C, hs, ws), np.float64)
+    for xi, yi, wgt, inb in bilinear_taps(ix, iy, hs, ws):
+        w_eff = np.where(inb, wgt, F32(0.0)).astype(np.float64)
+        flat = (yi * ws + xi).ravel()
+        contrib = (gout.reshape(C, -1).astype(np.float64) * w_eff.ravel()[None])
+        for c in range(C):
+            gimg[c] += np.bincount(flat, weights=contrib[c], minlength=hs * ws).reshape(hs, ws)
+    return gimg.astype(F32)
+
+
+def warp_variance_backward(key_feat, src_feats, src_projs, ref_proj_inv, depth_values, gvar):
+    """VJP of warp_variance (mvsnet.py:124-135 + blocks/utils.py:222-268): gvar (B,C,D,H,W) ->
+    (dkey (B,C,H,W), [dsrc_v (B,C,H,W)]).  d var / d x_v = 2 (x_v - mean) / (V+1) for every volume x_v (key included)."""
+    B, C, H, W = key_feat.shape
+    D = depth_values.shape[1]
+    nv = F32(len(src_feats) + 1)
+    grids = [homo_warp_grid(P, ref_proj_inv, depth_values, H, W) for P in src_projs]
+    vols = [np.repeat(key_feat[:, :, None], D, 2).astype(F32)]
+    for f, (ix, iy) in zip(src_feats, grids):
+        vols.append(np.stack([grid_sample_zeros(f[b], ix[b], iy[b]) for b in range(B)], 0))
+    mean = sum(vols) / nv
+    dkey = (gvar * F32(2.0) * (vols[0] - mean) / nv).sum(2).astype(F32)
+    dsrcs = []
+    for f, (ix, iy), x in zip(src_feats, grids, vols[1:]):
+        gx = (gvar * F32(2.0) * (x - mean) / nv).astype(F32)
+        dsrcs.append(np.stack([grid_sample_zeros_backward(gx[b], ix[b], iy[b], H, W) for b in range(B)], 0))
+    return dkey, dsrcs
+
+
+def sweep_corr_view_backward(feat_key, feat_src, us, vs, visible, gcorr):
+    """VJP of sweep_corr_view w.r.t. the two feature maps; the 0/1 mask is a constant (planesweep_corr.py:99-104)."""
+    N, C, h, w = feat_key.shape
+    hs, ws = feat_src.shape[-2:]
+    S = us.shape[1]
+    inv_sqrt_c = F32(1.0) / np.sqrt(F32(C))
+    dkey = np.zeros_like(feat_key, dtype=np.float64)
+    dsrc = np.zeros_like(feat_src, dtype=np.float64)
+    for n in range(N):
+        for s in range(S):
+            gx = F32(2.0) * us[n, s] / F32(ws) - F32(1.0)
+            gy = F32(2.0) * vs[n, s] / F32(hs) - F32(1.0)
+            ix, iy = unnormalize(gx, ws), unnormalize(gy, hs)
+            taps = bilinear_taps(ix, iy, hs, ws)
+            inb_sum = np.zeros((h, w), F32)
+            for xi, yi, wgt, inb in taps:
+                inb_sum += np.where(inb, wgt, F32(0.0))
+            m = np.where(inb_sum < F32(0.9999), F32(0.0), F32(1.0)) * visible[n, s].astype(F32)
+            coef = (gcorr[n, s] * m * inv_sqrt_c).astype(np.float64)  # (h,w)
+            for xi, yi, wgt, inb in taps:
+                w_eff = np.where(inb, wgt, F32(0.0)).astype(np.float64) * coef
+                dkey[n] += feat_src[n][:, yi, xi] * w_eff[None]
+                flat = (yi * ws + xi).ravel()
+                contrib = feat_key[n].reshape(C, -1).astype(np.float64) * w_eff.ravel()[None]
+                for c in range(C):
+                    dsrc[n, c] += np.bincount(flat, weights=contrib[c], minlength=hs * ws).reshape(hs, ws)
+    return dkey.astype(F32), dsrc.astype(F32)
+
+
+def planesweep_correlation_backward(feat_key, intrinsics_key, feat_sources, source_to_key_transforms, invdepths, gcorrs,
+                                    intrinsics_sources=None):
+    """VJP of planesweep_correlation w.r.t. feat_key and feat_sources: -> (dkey, [dsrc_v])."""
+    N, C, h, w = feat_key.shape
+    if intrinsics_sources is None:
+        intrinsics_sources = [intrinsics_key] * len(feat_sources)
+    inv = np.asarray(invdepths, F32).reshape(np.asarray(invdepths).shape[0], -1)
+    inv_n = np.broadcast_to(inv, (N, inv.shape[1]))
+    dkey = np.zeros_like(feat_key)
+    dsrcs = []
+    for fs, T, Ks, g in zip(feat_sources, source_to_key_transforms, intrinsics_sources, gcorrs):
+        co = epipolar_coeffs(intrinsics_key, Ks, T, h, w, fs.shape[2], fs.shape[3])
+        us, vs, vis = sweep_grids(co, inv_n)
+        dk, ds = sweep_corr_view_backward(feat_key, fs, us, vs, vis, g)
+        dkey = dkey + dk
+        dsrcs.append(ds)
+    return dkey, dsrcs
+
+
+def fuse_views_backward(corrs, masks, scores, gfused):
+    """VJP of fuse_views (learned_fusion.py:32-48) w.r.t. corrs[v] and scores[v]; masks and the fused mask are constants.
+    w = softmax_v(score) + 1e-9, u_v = w_v m_v, W = sum u, fused = fm * (sum c_v u_v) / (W + 1e-9)."""
+    V = len(corrs)
+    s = np.stack(scores, 0).astype(np.float64)
+    e = np.exp(s - s.max(0, keepdims=True))
+    p = e / e.sum(0, keepdims=True)  # softmax over views, (V,N,1,h,w)
+    u = [(p[v] + 1e-9) * masks[v] for v in range(V)]
+    W = sum(u)
+    fm = (W != 0).astype(np.float64)
+    num = sum(c * x for c, x in zip(corrs, u))
+    den = W + 1e-9
+    g = gfused.astype(np.float64) * fm
+    dcorrs = [(g * u[v] / den).astype(F32) for v in range(V)]
+    # d fused / d u_v = (c_v - num/den) / den ; u_v = (p_v + 1e-9) m_v ; p = softmax(score) over v, score broadcast over S
+    du = [g * (corrs[v] - num / den) / den * masks[v] for v in range(V)]           # = d loss / d p_v, per (N,S,h,w)
+    dp = np.stack([d.sum(1, keepdims=True) for d in du], 0)                        # scores are (N,1,h,w): sum over S
+    dscore = p * (dp - (p * dp).sum(0, keepdims=True))
+    return dcorrs, [dscore[v].astype(F32) for v in range(V)]

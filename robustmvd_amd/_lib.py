@@ -62,6 +62,12 @@ SIGNATURES = {
     "mvd_softmax_regress_f32": (_i, [_c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "mvd_bias_leaky_relu_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]),
     "mvd_arm_kernel_timing": (_i, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mvd_warp_variance_backward_workspace_bytes": (_sz, [_i]),
+    "mvd_warp_variance_backward_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p, _c_float_p] + [_i] * 6
+                                       + [_c_float_p, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_sweep_corr_backward_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, _pp] + [_i] * 8
+                                    + [_c_float_p, _pp, ctypes.c_void_p]),
+    "mvd_fuse_views_backward_f32": (_i, [_pp, _pp, _pp, _c_float_p] + [_i] * 5 + [_pp, _pp, ctypes.c_void_p]),
     "mvd_resize_order1_f32": (_i, [_c_float_p, _c_float_p, ctypes.c_longlong, _i, _i, _i, _i, ctypes.c_void_p]),
     "mvd_nchw_to_nhwc_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),
     "mvd_nhwc_to_nchw_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),

@@ -57,10 +57,22 @@ class PlanesweepCorrelation(nn.Module):
                                                                     sampling_type).to(device)
         return self._invdepth_cache[ckey]
 
-    @ops.inference_only
     def forward(self, feat_key, intrinsics_key, feat_sources, source_to_key_transforms, intrinsics_sources=None,
                 num_sampling_points=None, min_depth=None, max_depth=None, sampling_invdepths=None,
                 sampling_type="linear_invdepth"):
+        """Differentiable w.r.t. feat_key and feat_sources like the reference's correlate() (planesweep_corr.py:514-521):
+        when autograd is recording and a feature map requires grad, the sweep goes through ops.sweep_corr_autograd (the
+        engine's VJP kernel, mvd_sweep_corr_backward_f32); otherwise through the plain inference entry point.  The
+        sampling grids and masks are constants in both (the reference computes them under no_grad, :436,464,489)."""
+        args = (feat_key, intrinsics_key, feat_sources, source_to_key_transforms, intrinsics_sources, num_sampling_points,
+                min_depth, max_depth, sampling_invdepths, sampling_type)
+        if ops.needs_grad(feat_key, feat_sources):
+            return self._forward(ops.sweep_corr_autograd, *args)
+        with torch.no_grad():
+            return self._forward(ops.sweep_corr, *args)
+
+    def _forward(self, sweep, feat_key, intrinsics_key, feat_sources, source_to_key_transforms, intrinsics_sources,
+                 num_sampling_points, min_depth, max_depth, sampling_invdepths, sampling_type):
         if intrinsics_sources is None:
             intrinsics_sources = [intrinsics_key] * len(feat_sources)
         if not (len(feat_sources) == len(source_to_key_transforms) == len(intrinsics_sources)):
@@ -92,8 +104,8 @@ class PlanesweepCorrelation(nn.Module):
         for i, f in enumerate(feat_sources):
             groups.setdefault(tuple(f.shape[-2:]), []).append(i)
         for idxs in groups.values():
-            c, m = ops.sweep_corr(feat_key, [feat_sources[i] for i in idxs], intrinsics_key,
-                                  [intrinsics_sources[i] for i in idxs], [source_to_key_transforms[i] for i in idxs], inv)
+            c, m = sweep(feat_key, [feat_sources[i] for i in idxs], intrinsics_key,
+                         [intrinsics_sources[i] for i in idxs], [source_to_key_transforms[i] for i in idxs], inv)
             for i, ci, mi in zip(idxs, c, m):
                 corrs[i], masks[i] = ci, mi
         return corrs, masks, inv[:, :, None, None]
@@ -113,7 +125,10 @@ class LearnedFusion(nn.Module):
             return corrs[0], masks[0]
         n = corrs[0].shape[0]
         scores = self.corr_to_view_weight(torch.cat(list(corrs), 0))  # one batched MIOpen call for all views
-        return ops.fuse_views(corrs, masks, list(torch.split(scores, n, 0)))
+        scores = list(torch.split(scores, n, 0))
+        if ops.needs_grad(corrs, scores):  # training: the engine's VJP kernel (mvd_fuse_views_backward_f32)
+            return ops.fuse_views_autograd(corrs, masks, scores)
+        return ops.fuse_views(corrs, masks, scores)
 
 
 def depth_regression(p, depth_values):

@@ -243,7 +243,7 @@ class MVSNet(nn.Module):
         return to_numpy(pred), to_numpy(aux)
 
 
-@register_model(trainable=False)  # the reference lists it as trainable; this engine's sweep + fusion have no backward yet
+@register_model  # trainable like the reference's: the sweep (K1) and the fusion (K2) back-propagate through the engine's VJP kernels
 def robust_mvd(pretrained=True, weights=None, train=False, num_gpus=1, **kwargs):
     if pretrained and weights is None:
         raise RuntimeError("robust_mvd: the pretrained weights are URL-only (robust_mvd.py:153) and there is no network; "

@@ -441,3 +441,167 @@ def from_channels_last_3d(y):
         rc = lib.mvd_nhwc_to_nchw_f32(L.ptr(y), L.ptr(x), B, C, D * h * w, L.stream_of(y))
     L.check(rc, "mvd_nhwc_to_nchw_f32")
     return x
+
+
+# ------------------------------------------------------------------------------------------------
+# Differentiable forms: torch.autograd.Function wrappers whose backward runs the engine's VJP
+# kernels (include/mvd.h "Backward of the sweep operators").  Gradients flow to the FEATURE MAPS (and, for the fusion, to
+# the score maps); calibration, depth samples and masks are constants, exactly as in the reference
+# (planesweep_corr.py:436,464,489 compute the grids under no_grad).
+# ------------------------------------------------------------------------------------------------
+def _bordered_channels_last(x):
+    """(N,C,h,w) -> zero-bordered channel-last (N,h+3,w+3,C) with the map at (1,1): the layout the kernels gather from."""
+    n, c, h, w = x.shape
+    out = torch.zeros((n, h + 3, w + 3, c), dtype=torch.float32, device=x.device)
+    out[:, 1:h + 1, 1:w + 1] = x.permute(0, 2, 3, 1)
+    return out
+
+
+def _interior_nchw(g, h, w):
+    return g[:, 1:h + 1, 1:w + 1].permute(0, 3, 1, 2).contiguous()
+
+
+class _WarpVariance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, key_proj_inv, depth_values, n_views, key_feat, *rest):
+        srcs, projs = list(rest[:n_views]), list(rest[n_views:])
+        ctx.save_for_backward(key_proj_inv, depth_values, key_feat, *srcs, *projs)
+        ctx.n_views = n_views
+        return warp_variance(key_feat.detach(), [s.detach() for s in srcs], projs, key_proj_inv, depth_values)
+
+    @staticmethod
+    def backward(ctx, gvar):
+        lib = L.load()
+        V = ctx.n_views
+        kpi, dv, key = ctx.saved_tensors[:3]
+        srcs, projs = list(ctx.saved_tensors[3:3 + V]), list(ctx.saved_tensors[3 + V:])
+        B, C, h, w = key.shape
+        D = dv.shape[1]
+        dev = key.device
+        with torch.no_grad():
+            kb = _bordered_channels_last(key.float())
+            sb = [_bordered_channels_last(s.float()) for s in srcs]
+            g = gvar.float().permute(0, 2, 3, 4, 1).contiguous()  # (B,D,h,w,C)
+            gk = torch.empty_like(kb)
+            gs = [torch.empty_like(kb) for _ in range(V)]
+            pr = [L.as_f32(p, "src_proj", (B, 4, 4), dev) for p in projs]
+            wsb = lib.mvd_warp_variance_backward_workspace_bytes(B)
+            wsp = _workspace(wsb, dev)
+            a_s, k1 = L.ptr_array(sb)
+            a_p, k2 = L.ptr_array(pr)
+            a_g, k3 = L.ptr_array(gs)
+            with torch.cuda.device(dev):
+                rc = lib.mvd_warp_variance_backward_f32(L.ptr(kb), a_s, a_p, L.ptr(L.as_f32(kpi, "key_proj_inv", (B, 4, 4), dev)),
+                                                        L.ptr(L.as_f32(dv, "depth_values", (B, D), dev)), L.ptr(g), B, C, D, h, w,
+                                                        V, L.ptr(gk), a_g, L.ptr(wsp), wsb, L.stream_of(kb))
+            L.check(rc, "mvd_warp_variance_backward_f32")
+            out = [None, None, None, _interior_nchw(gk, h, w)] + [_interior_nchw(x, h, w) for x in gs] + [None] * V
+        return tuple(out)
+
+
+def warp_variance_autograd(key_feat, src_feats, src_projs, key_proj_inv, depth_values):
+    """Differentiable K3: like warp_variance (reference layout (B,C,D,h,w)), with gradients to key_feat and src_feats."""
+    srcs = _views(src_feats, "src_feats")
+    return _WarpVariance.apply(key_proj_inv, depth_values, len(srcs), key_feat, *srcs, *_views(src_projs, "src_projs", len(srcs)))
+
+
+class _SweepCorr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, K_key, invdepths, n_views, feat_key, *rest):
+        V = n_views
+        srcs, Ks, Ts = list(rest[:V]), list(rest[V:2 * V]), list(rest[2 * V:])
+        corrs, masks = sweep_corr(feat_key.detach(), [s.detach() for s in srcs], K_key, Ks, Ts, invdepths)
+        ctx.save_for_backward(K_key, invdepths, feat_key, *srcs, *Ks, *Ts)
+        ctx.n_views = V
+        ctx.mark_non_differentiable(*masks)
+        return tuple(corrs) + tuple(masks)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = L.load()
+        V = ctx.n_views
+        Kk, inv, fk = ctx.saved_tensors[:3]
+        srcs = list(ctx.saved_tensors[3:3 + V])
+        Ks, Ts = list(ctx.saved_tensors[3 + V:3 + 2 * V]), list(ctx.saved_tensors[3 + 2 * V:])
+        N, C, h, w = fk.shape
+        hs, ws = srcs[0].shape[-2:]
+        S = inv.shape[1]
+        dev = fk.device
+        with torch.no_grad():
+            key = fk.float().permute(0, 2, 3, 1).contiguous()
+            sb = [_bordered_channels_last(s.float()) for s in srcs]
+            gc = [(g if g is not None else torch.zeros((N, S, h, w), device=dev)).float().contiguous() for g in grads[:V]]
+            gk = torch.empty_like(key)
+            gs = [torch.empty_like(sb[0]) for _ in range(V)]
+            Ksf = [L.as_f32(k, "K_src", (N, 3, 3), dev) for k in Ks]
+            Tsf = [L.as_f32(t, "T", (N, 4, 4), dev) for t in Ts]
+            a_s, k1 = L.ptr_array(sb)
+            a_K, k2 = L.ptr_array(Ksf)
+            a_T, k3 = L.ptr_array(Tsf)
+            a_gc, k4 = L.ptr_array(gc)
+            a_gs, k5 = L.ptr_array(gs)
+            invf = L.as_f32(inv, "invdepths", device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.mvd_sweep_corr_backward_f32(L.ptr(key), a_s, L.ptr(L.as_f32(Kk, "K_key", (N, 3, 3), dev)), a_K, a_T,
+                                                     L.ptr(invf), int(invf.shape[0] == N and N > 1), a_gc, N, C, h, w, hs, ws, S,
+                                                     V, L.ptr(gk), a_gs, L.stream_of(key))
+            L.check(rc, "mvd_sweep_corr_backward_f32")
+            out = [None, None, None, gk.permute(0, 3, 1, 2).contiguous()] + [_interior_nchw(x, hs, ws) for x in gs] + [None] * (2 * V)
+        return tuple(out)
+
+
+def sweep_corr_autograd(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths):
+    """Differentiable K1: returns (corrs[V], masks[V]); gradients to feat_key and feat_sources."""
+    srcs = _views(feat_sources, "feat_sources")
+    V = len(srcs)
+    outs = _SweepCorr.apply(K_key, invdepths, V, feat_key, *srcs, *_views(K_sources, "intrinsics_sources", V),
+                            *_views(T_src2key, "source_to_key_transforms", V))
+    return list(outs[:V]), list(outs[V:])
+
+
+class _FuseViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n_views, *rest):
+        V = n_views
+        corrs, masks, scores = list(rest[:V]), list(rest[V:2 * V]), list(rest[2 * V:])
+        fused, fmask = fuse_views([c.detach() for c in corrs], [m.detach() for m in masks], [s.detach() for s in scores])
+        ctx.save_for_backward(*corrs, *masks, *scores)
+        ctx.n_views = V
+        ctx.mark_non_differentiable(fmask)
+        return fused, fmask
+
+    @staticmethod
+    def backward(ctx, gfused, _gmask):
+        lib = L.load()
+        V = ctx.n_views
+        t = ctx.saved_tensors
+        corrs, masks, scores = list(t[:V]), list(t[V:2 * V]), list(t[2 * V:])
+        N, S, h, w = corrs[0].shape
+        dev = corrs[0].device
+        with torch.no_grad():
+            cs = [L.as_f32(c, "corr", (N, S, h, w), dev) for c in corrs]
+            ms = [L.as_f32(m, "mask", (N, S, h, w), dev) for m in masks]
+            ss = [L.as_f32(s, "score", (N, 1, h, w), dev) for s in scores]
+            g = gfused.float().contiguous()
+            gcs = [torch.empty_like(cs[0]) for _ in range(V)]
+            gss = [torch.empty_like(ss[0]) for _ in range(V)]
+            a_c, k1 = L.ptr_array(cs)
+            a_m, k2 = L.ptr_array(ms)
+            a_s, k3 = L.ptr_array(ss)
+            a_gc, k4 = L.ptr_array(gcs)
+            a_gs, k5 = L.ptr_array(gss)
+            with torch.cuda.device(dev):
+                rc = lib.mvd_fuse_views_backward_f32(a_c, a_m, a_s, L.ptr(g), N, S, h, w, V, a_gc, a_gs, L.stream_of(g))
+            L.check(rc, "mvd_fuse_views_backward_f32")
+        return (None,) + tuple(gcs) + (None,) * V + tuple(gss)
+
+
+def fuse_views_autograd(corrs, masks, scores):
+    """Differentiable K2: gradients to corrs and scores."""
+    corrs = _views(corrs, "corrs")
+    V = len(corrs)
+    return _FuseViews.apply(V, *corrs, *_views(masks, "masks", V), *_views(scores, "scores", V))
+
+
+def needs_grad(*objs):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in _tensors(objs))

@@ -345,7 +345,80 @@ def g8():
          depth=pred["depth"].numpy(), depth_uncertainty=pred["depth_uncertainty"].numpy())
 
 
+def g10():
+    """Gradients by autograd THROUGH THE REFERENCE (backward of K1 / K3 w.r.t. the feature maps,
+    grids under no_grad; multi_view_depth_training.py:231-246 back-propagates through exactly these ops), plus
+    LearnedFusion's.  loss = sum(output * G) with a seeded random G, so the stored gradients are vector-Jacobian products."""
+    out = {}
+    with torch.enable_grad():
+        # --- K3: homo_warp + variance (blocks/utils.py:222-268, mvsnet.py:124-135) on the inputs of g4_warpvar_a / _c
+        for name in ("a", "c"):
+            g = np.load(os.path.join(HERE, f"g4_warpvar_{name}.npz"))
+            V = len([k for k in g.files if k.startswith("src_proj")])
+            feats = [t(g[f"feat{i}"]).requires_grad_(True) for i in range(V + 1)]
+            depth, key_inv = t(g["depth_values"]), t(g["key_proj_inv"])
+            D = depth.shape[1]
+            vol_sum = feats[0].unsqueeze(2).repeat(1, 1, D, 1, 1)
+            vol_sq = vol_sum ** 2
+            for v in range(V):
+                wv = ref.blocks_utils.homo_warp(feats[v + 1], t(g[f"src_proj{v}"]), key_inv, depth)
+                vol_sum = vol_sum + wv
+                vol_sq = vol_sq + wv ** 2
+            var = vol_sq / (V + 1) - (vol_sum / (V + 1)) ** 2
+            np.testing.assert_allclose(var.detach().numpy(), g["variance"], atol=1e-5, rtol=1e-5)
+            G = gc.rng_array(1000 + ord(name), tuple(var.shape))
+            (var * t(G)).sum().backward()
+            out[f"k3_{name}_G_seed"] = np.int64(1000 + ord(name))
+            for i, f in enumerate(feats):
+                out[f"k3_{name}_dfeat{i}"] = f.grad.numpy()
+        # --- K1: PlanesweepCorrelation (planesweep_corr.py:396-521), C = 64, 12x18, S = 8
+        K_px, T_sd = sample_data_calib()
+        K_rel = (K_px / np.array([[1280.0] * 3, [720.0] * 3, [1.0] * 3], np.float32))[None]
+        Tb = np.eye(4, dtype=np.float32)
+        Tb[:3, :3] = gc.rot_xyz(0.1, 0.7, -0.05)
+        Tb[:3, 3] = [0.2, -0.1, -0.6]
+        for name, Ts, kw in (("toy", [T_sd[0][None], T_sd[1][None]], dict(num_sampling_points=8, min_depth=0.4, max_depth=1000.0)),
+                             ("behind", [Tb[None]], dict(num_sampling_points=8, min_depth=0.4, max_depth=5.0,
+                                                         sampling_type="linear_depth"))):
+            V = len(Ts)
+            fk = t(gc.rng_array(1101, (1, 64, 12, 18))).requires_grad_(True)
+            fs = [t(gc.rng_array(1102 + i, (1, 64, 12, 18))).requires_grad_(True) for i in range(V)]
+            blk = ref.planesweep_corr.PlanesweepCorrelation()
+            corrs, masks, inv = blk(feat_key=fk, intrinsics_key=t(K_rel), feat_sources=fs,
+                                    source_to_key_transforms=[t(T) for T in Ts], **kw)
+            loss = sum((c * t(gc.rng_array(1110 + v, tuple(c.shape)))).sum() for v, c in enumerate(corrs))
+            loss.backward()
+            out[f"k1_{name}_K"] = K_rel
+            out[f"k1_{name}_invdepths"] = inv.detach().numpy()
+            for v in range(V):
+                out[f"k1_{name}_T{v}"] = Ts[v]
+                out[f"k1_{name}_corr{v}"] = corrs[v].detach().numpy()
+                out[f"k1_{name}_dsrc{v}"] = fs[v].grad.numpy()
+            out[f"k1_{name}_dkey"] = fk.grad.numpy()
+        # --- LearnedFusion (learned_fusion.py:24-54), V = 3: gradients w.r.t. the correlation volumes and the parameters
+        shapes = {"corr_to_view_weight.0.weight": (128, 256, 3, 3), "corr_to_view_weight.0.bias": (128,),
+                  "corr_to_view_weight.2.weight": (1, 128, 1, 1), "corr_to_view_weight.2.bias": (1,)}
+        sd = gc.fill_state_dict(shapes, 1200)
+        m = ref.learned_fusion.LearnedFusion().eval()
+        m.load_state_dict({k: t(v) for k, v in sd.items()})
+        rng = np.random.default_rng(1201)
+        V = 3
+        masks = [(rng.uniform(size=(1, 256, 10, 14)) > 0.35).astype(np.float32) for _ in range(V)]
+        for mk in masks:
+            mk[:, 5:9, 6:, 9:] = 0
+        corrs = [t(rng.standard_normal((1, 256, 10, 14)).astype(np.float32) * mk).requires_grad_(True) for mk in masks]
+        fused, fmask = m(corrs, [t(mk) for mk in masks])
+        (fused * t(gc.rng_array(1202, tuple(fused.shape)))).sum().backward()
+        out["k2_fused"] = fused.detach().numpy()
+        for v in range(V):
+            out[f"k2_mask{v}"] = np.packbits(masks[v].astype(np.uint8).ravel())
+            out[f"k2_dcorr{v}"] = corrs[v].grad.numpy()
+        for k, prm in m.named_parameters():
+            out["k2_d" + k] = prm.grad.numpy()
+    save("g10_grads", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for g in which:
         globals()[g]()

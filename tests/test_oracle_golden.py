@@ -257,3 +257,73 @@ def test_pipeline_robustmvd_g7():
     pred = PL.robustmvd_forward(images, [np.eye(4, dtype=np.float32)[None], g["T0"][None]], [K_rel, K_rel], 0, sd)
     np.testing.assert_allclose(pred["invdepth"], g["invdepth"][None], atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(pred["invdepth_log_b"], g["invdepth_log_b"][None], atol=1e-4, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# backward restatements against autograd through the reference (g10)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["a", "c"])
+def test_g10_warp_variance_backward(name):
+    g, g4 = load_golden("g10_grads"), load_golden(f"g4_warpvar_{name}")
+    V = len([k for k in g4.files if k.startswith("src_proj")])
+    feats = [g4[f"feat{i}"] for i in range(V + 1)]
+    G = gc.rng_array(int(g[f"k3_{name}_G_seed"]), g4["variance"].shape)
+    dkey, dsrcs = O.warp_variance_backward(feats[0], feats[1:], [g4[f"src_proj{v}"] for v in range(V)], g4["key_proj_inv"],
+                                           g4["depth_values"], G)
+    np.testing.assert_allclose(dkey, g[f"k3_{name}_dfeat0"], atol=2e-4, rtol=1e-4)
+    for v in range(V):
+        np.testing.assert_allclose(dsrcs[v], g[f"k3_{name}_dfeat{v + 1}"], atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name,V", [("toy", 2), ("behind", 1)])
+def test_g10_sweep_corr_backward(name, V):
+    g = load_golden("g10_grads")
+    fk = gc.rng_array(1101, (1, 64, 12, 18))
+    fs = [gc.rng_array(1102 + i, (1, 64, 12, 18)) for i in range(V)]
+    Ts = [g[f"k1_{name}_T{v}"] for v in range(V)]
+    K = g[f"k1_{name}_K"]
+    inv = g[f"k1_{name}_invdepths"][:, :, 0, 0]
+    corrs, _, _ = O.planesweep_correlation(fk, K, fs, Ts, sampling_invdepths=inv)
+    Gs = [gc.rng_array(1110 + v, corrs[v].shape) for v in range(V)]
+    for v in range(V):
+        np.testing.assert_allclose(corrs[v], g[f"k1_{name}_corr{v}"], atol=ATOL, rtol=RTOL)
+    dkey, dsrcs = O.planesweep_correlation_backward(fk, K, fs, Ts, inv, Gs)
+    np.testing.assert_allclose(dkey, g[f"k1_{name}_dkey"], atol=2e-4, rtol=1e-4)
+    for v in range(V):
+        np.testing.assert_allclose(dsrcs[v], g[f"k1_{name}_dsrc{v}"], atol=2e-4, rtol=1e-4)
+
+
+def test_g10_fusion_backward():
+    """K2's VJP w.r.t. the correlation volumes (checked directly) and w.r.t. the score maps (checked through the
+    parameter gradients of the score convolutions, which torch back-propagates from dscore)."""
+    import torch
+    import torch.nn.functional as F
+    g = load_golden("g10_grads")
+    shapes = {"corr_to_view_weight.0.weight": (128, 256, 3, 3), "corr_to_view_weight.0.bias": (128,),
+              "corr_to_view_weight.2.weight": (1, 128, 1, 1), "corr_to_view_weight.2.bias": (1,)}
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in gc.fill_state_dict(shapes, 1200).items()}
+    rng = np.random.default_rng(1201)
+    V = 3
+    masks = [(rng.uniform(size=(1, 256, 10, 14)) > 0.35).astype(np.float32) for _ in range(V)]
+    for mk in masks:
+        mk[:, 5:9, 6:, 9:] = 0
+    corrs = [rng.standard_normal((1, 256, 10, 14)).astype(np.float32) * mk for mk in masks]
+    scores_t = []
+    for c in corrs:
+        hid = F.relu(F.conv2d(torch.from_numpy(c), sd["corr_to_view_weight.0.weight"], sd["corr_to_view_weight.0.bias"], 1, 1))
+        scores_t.append(F.conv2d(hid, sd["corr_to_view_weight.2.weight"], sd["corr_to_view_weight.2.bias"]))
+    scores = [s.detach().numpy() for s in scores_t]
+    fused, _ = O.fuse_views(corrs, masks, scores)
+    np.testing.assert_allclose(fused, g["k2_fused"], atol=ATOL, rtol=RTOL)
+    G = gc.rng_array(1202, fused.shape)
+    dcorrs, dscores = O.fuse_views_backward(corrs, masks, scores, G)
+    torch.autograd.backward(scores_t, [torch.from_numpy(d) for d in dscores])
+    # the reference's gradient w.r.t. corr_v also contains the path through the score convolutions
+    for v in range(V):
+        cv = torch.from_numpy(corrs[v]).requires_grad_(True)
+        hid = F.relu(F.conv2d(cv, sd["corr_to_view_weight.0.weight"].detach(), sd["corr_to_view_weight.0.bias"].detach(), 1, 1))
+        sc = F.conv2d(hid, sd["corr_to_view_weight.2.weight"].detach(), sd["corr_to_view_weight.2.bias"].detach())
+        sc.backward(torch.from_numpy(dscores[v]))
+        np.testing.assert_allclose(dcorrs[v] + cv.grad.numpy(), g[f"k2_dcorr{v}"], atol=2e-4, rtol=1e-3)
+    for k, prm in sd.items():
+        np.testing.assert_allclose(prm.grad.numpy(), g["k2_d" + k], atol=5e-4, rtol=1e-3)

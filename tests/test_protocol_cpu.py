@@ -106,20 +106,20 @@ def test_product_sampling_invdepths_match_reference_golden():
 
 
 def test_inference_only_ops_refuse_autograd():
-    """the reference's sweep and fusion are differentiable; this engine's are not (yet), so recording a
-    graph through them must fail loudly instead of cutting the gradients silently.  The check runs before any device
-    validation, so it can be exercised without a GPU."""
+    """the reference's sweep and fusion are differentiable.  The plain (inference) entry points of this engine
+    refuse to record a graph instead of cutting the gradients silently; the operator modules route training through the
+    VJP kernels (ops.*_autograd), which need the GPU like everything else: on a CPU tensor that fails loudly too."""
     import robustmvd_amd as R
     from robustmvd_amd import ops
     x = torch.zeros(1, 4, 2, 2, requires_grad=True)
     with pytest.raises(RuntimeError, match="inference-only"):
         ops.fuse_views([x, x], [x.detach(), x.detach()], [x.detach()[:, :1]] * 2)
-    with pytest.raises(RuntimeError, match="inference-only"):
+    with pytest.raises(ValueError, match="needs a cuda"):  # differentiable path: reaches the engine, which has no CPU form
         R.PlanesweepCorrelation()(x, torch.eye(3)[None], [x], [torch.eye(4)[None]], num_sampling_points=4, min_depth=1.0,
                                   max_depth=2.0)
     with pytest.raises(RuntimeError, match="inference-only"):
         ops.softmax_regress(x, torch.zeros(1, 4))
     with torch.no_grad(), pytest.raises(ValueError, match="cuda"):  # under no_grad the same call reaches validation
         ops.softmax_regress(x, torch.zeros(1, 4))
-    # a model whose sweep cannot back-propagate is not offered for training
-    assert R.list_models(trainable_only=True) == []
+    # robust_mvd is trainable again (K1 / K2 have backward kernels); the MVSNet path (folded BN, HIP layers) is not
+    assert R.list_models(trainable_only=True) == ["robust_mvd"]
