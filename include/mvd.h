@@ -209,6 +209,25 @@ int mvd_arm_kernel_timing(void* start_event, void* stop_event);
  * The convolutions themselves stay on the vendor library; this replaces the two elementwise passes after each. */
 int mvd_bias_leaky_relu_f32(float* x, const float* bias, int N, int C, long long HW, float slope, mvd_stream_t stream);
 
+/* Other consumers of the sweep as reduction modes of one generic kernel: CVP-MVSNet's variance
+ * with PER-PIXEL depth hypotheses (rmvd/models/cvp_mvsnet.py:125-168, blocks/cvp_mvsnet_components.py:375-456) and
+ * Vis-MVSNet's group-wise correlation (blocks/utils.py:71-89, blocks/vis_mvsnet_singlestage.py:230-260).
+ *   key_feat (B,C,h,w); src_feat[v] (B,C,h,w); M[v] (B,3,4) = [R | t] with (X,Y,Z) = R (x+o, y+o, 1)^T d + t;
+ *   depth (B,D), or (B,D,h,w) when depth_per_pixel; sample index = (X/Z) * scale + bias, bilinear, zero padding
+ *   (homo_warp / cvp homo_warping: o = 0, scale = W/(W-1), H/(H-1), bias = -0.5; vis homography_warping: o = 0.5, scale = 1,
+ *   bias = -0.5);
+ *   mode MVD_REDUCE_VARIANCE / MVD_REDUCE_VARIANCE_KEYSQ: out[0] (B,C,D,h,w) — KEYSQ reproduces the reference's aliasing
+ *   of the running sum with the squared key volume (cvp_mvsnet.py:129-130);
+ *   mode MVD_REDUCE_GROUPCORR: out[v] (B,groups,D,h,w) = sum over each group's channels of key * warped source v. */
+#define MVD_REDUCE_VARIANCE 0
+#define MVD_REDUCE_VARIANCE_KEYSQ 1
+#define MVD_REDUCE_GROUPCORR 2
+size_t mvd_sweep_reduce_workspace_bytes(int B, int C, int h, int w, int V);
+int mvd_sweep_reduce_f32(const float* key_feat, const float* const* src_feat, const float* const* M, const float* depth,
+                         int depth_per_pixel, float pix_offset, float scale_x, float scale_y, float bias, int mode, int groups,
+                         int B, int C, int D, int h, int w, int V, float* const* out, void* workspace, size_t workspace_bytes,
+                         mvd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Backward of the sweep operators w.r.t. the feature maps, for the training loop
  * (rmvd/train/multi_view_depth_training.py:231-246).  The sampling grids carry no gradient (planesweep_corr.py:436,464,489;

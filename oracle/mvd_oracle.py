@@ -529,3 +529,92 @@ def fuse_views_backward(corrs, masks, scores, gfused):
     dp = np.stack([d.sum(1, keepdims=True) for d in du], 0)                        # scores are (N,1,h,w): sum over S
     dscore = p * (dp - (p * dp).sum(0, keepdims=True))
     return dcorrs, [dscore[v].astype(F32) for v in range(V)]
+
+
+# =============================================================================================
+# Other consumers of the sweep, restated from the reference's CUDA-only code
+# =============================================================================================
+def cvp_proj_cost(ref_feature, src_features, ref_in, src_in, ref_ex, src_ex, depth_hypos, alias_bug=True):
+    """proj_cost, rmvd/models/blocks/cvp_mvsnet_components.py:375-456 (depth_hypos (B,D,H,W)), and the coarse level of
+    CVPMVSNet.forward with homo_warping (:192-245; depth_hypos (B,D)).  alias_bug=True follows the reference literally:
+    `volume_sum = ref_volume; volume_sq_sum = volume_sum.pow_(2)` squares the one tensor both names refer to
+    (cvp_mvsnet_components.py:393-394, cvp_mvsnet.py:129-130)."""
+    B, C, H, W = ref_feature.shape
+    dh = np.asarray(depth_hypos, F32)
+    D = dh.shape[1]
+    if dh.ndim == 2:
+        dh = np.broadcast_to(dh[:, :, None, None], (B, D, H, W))
+    nsrc = len(src_features)
+    vol = np.repeat(ref_feature[:, :, None], D, 2).astype(F32)
+    vsq = vol ** 2
+    vsum = vsq.copy() if alias_bug else vol
+    last = np.array([[0, 0, 0, 1.0]], F32)
+    x = np.arange(W, dtype=F32)[None, None, None, :]
+    y = np.arange(H, dtype=F32)[None, None, :, None]
+    for s in range(nsrc):
+        warped = np.zeros((B, C, D, H, W), F32)
+        for b in range(B):
+            src_proj = np.concatenate([(src_in[b, s] @ src_ex[b, s][:3]).astype(F32), last], 0)
+            ref_proj = np.concatenate([(ref_in[b] @ ref_ex[b][:3]).astype(F32), last], 0)
+            proj = (src_proj @ np.linalg.inv(ref_proj)).astype(F32)
+            R, T = proj[:3, :3], proj[:3, 3]
+            d = dh[b][None]  # (1,D,H,W)
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                # rot @ (x, y, 1), then * depth, then + trans (cvp_mvsnet_components.py:429-436)
+                rx = R[0, 0] * x + R[0, 1] * y + R[0, 2]
+                ry = R[1, 0] * x + R[1, 1] * y + R[1, 2]
+                rz = R[2, 0] * x + R[2, 1] * y + R[2, 2]
+                X, Y, Z = rx * d + T[0], ry * d + T[1], rz * d + T[2]
+                gx = (X / Z) / F32((W - 1) / 2) - F32(1.0)
+                gy = (Y / Z) / F32((H - 1) / 2) - F32(1.0)
+                ix, iy = unnormalize(gx, W).astype(F32)[0], unnormalize(gy, H).astype(F32)[0]
+            warped[b] = grid_sample_zeros(src_features[s][b], ix, iy)
+        vsum = vsum + warped
+        vsq = vsq + warped ** 2
+    return (vsq / F32(nsrc + 1) - (vsum / F32(nsrc + 1)) ** 2).astype(F32)
+
+
+def vis_homographies(left_cam, right_cam, depth_num, depth_start, depth_interval):
+    """get_homographies, rmvd/models/blocks/utils.py:95-152 (inv=False): cams (n,2,4,4); depth_start / depth_interval
+    (n,1,1,1) or (n,1,h,w) -> (n,d,h|1,w|1,3,3)."""
+    n = left_cam.shape[0]
+    d = depth_num
+    R_l, R_r = left_cam[:, 0, :3, :3], right_cam[:, 0, :3, :3]
+    t_l, t_r = left_cam[:, 0, :3, 3:4], right_cam[:, 0, :3, 3:4]
+    K_l, K_r = left_cam[:, 1, :3, :3], right_cam[:, 1, :3, :3]
+    depth = depth_start + depth_interval * np.arange(d, dtype=F32).reshape(1, d, 1, 1)
+    depth = depth[..., None, None].astype(F32)
+    K_l_inv = np.linalg.inv(K_l.astype(F32)).astype(F32)
+    fronto = R_l[:, 2:3, :3]
+    c_l = -np.swapaxes(R_l, -2, -1) @ t_l
+    c_r = -np.swapaxes(R_r, -2, -1) @ t_r
+    temp = ((c_r - c_l) @ fronto).reshape(n, 1, 1, 1, 3, 3)
+    mm0 = np.eye(3, dtype=F32).reshape(1, 1, 1, 1, 3, 3) - temp / (depth + F32(1e-9))
+    mm1 = (np.swapaxes(R_l, -2, -1) @ K_l_inv).reshape(n, 1, 1, 1, 3, 3)
+    return (K_r.reshape(n, 1, 1, 1, 3, 3) @ R_r.reshape(n, 1, 1, 1, 3, 3) @ (mm0 @ mm1)).astype(F32)
+
+
+def vis_cost_volumes(ref_feat, ref_cam, srcs_feat, srcs_cam, depth_num, depth_start, depth_interval, groups=8):
+    """SingleStage.build_cost_volume (vis_mvsnet_singlestage.py:86-122, s_scale = d_scale = 1) + groupwise_correlation
+    (blocks/utils.py:71-89) per source view: homography_warping (:176-186) maps pixel centres (x+0.5, y+0.5), divides by
+    z + 1e-9, interpolate() (:163-172) normalises by the size, clamps to +-1.1 and samples with zero padding."""
+    n, C, h, w = ref_feat.shape
+    xs = (np.arange(w, dtype=F32) + F32(0.5))[None, :].repeat(h, 0)
+    ys = (np.arange(h, dtype=F32) + F32(0.5))[:, None].repeat(w, 1)
+    grid = np.stack([xs, ys, np.ones_like(xs)], -1)[..., None]  # (h,w,3,1)
+    outs = []
+    for sf, sc in zip(srcs_feat, srcs_cam):
+        Hs = vis_homographies(ref_cam, sc, depth_num, depth_start, depth_interval)  # (n,d,h|1,w|1,3,3)
+        vol = np.zeros((n, groups, depth_num, h, w), F32)
+        for b in range(n):
+            for k in range(depth_num):
+                with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                    wc = (Hs[b, k] @ grid)[..., 0]  # (h,w,3)
+                    cx = wc[..., 0] / (wc[..., 2] + F32(1e-9))
+                    cy = wc[..., 1] / (wc[..., 2] + F32(1e-9))
+                    gx = np.clip(cx / F32(w) * F32(2) - F32(1), F32(-1.1), F32(1.1))
+                    gy = np.clip(cy / F32(h) * F32(2) - F32(1), F32(-1.1), F32(1.1))
+                    warped = grid_sample_zeros(sf[b], unnormalize(gx, w).astype(F32), unnormalize(gy, h).astype(F32))
+                vol[b, :, k] = (ref_feat[b] * warped).reshape(groups, C // groups, h, w).sum(1)
+        outs.append(vol)
+    return outs

@@ -14,3 +14,4 @@ from .blocks import (PlanesweepCorrelation, LearnedFusion, CostRegNet, homo_warp
                      compute_sampling_invdepths)
 from .models import RobustMVD, MVSNet  # noqa: F401
 from .serving import FramePipeline  # noqa: F401
+from .sweep_modes import cvp_proj_cost, vis_cost_volumes, sweep_reduce  # noqa: F401

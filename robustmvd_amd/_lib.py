@@ -25,6 +25,9 @@ DECONV3D_STRIDE2 = 2
 LAYOUT_NCHW = 0
 LAYOUT_NHWC = 1
 LAYOUT_NHWC_BORDER = 2
+REDUCE_VARIANCE = 0
+REDUCE_VARIANCE_KEYSQ = 1
+REDUCE_GROUPCORR = 2
 
 _c_float_p = ctypes.c_void_p
 _pp = ctypes.POINTER(ctypes.c_void_p)
@@ -68,6 +71,9 @@ SIGNATURES = {
     "mvd_sweep_corr_backward_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, _pp] + [_i] * 8
                                     + [_c_float_p, _pp, ctypes.c_void_p]),
     "mvd_fuse_views_backward_f32": (_i, [_pp, _pp, _pp, _c_float_p] + [_i] * 5 + [_pp, _pp, ctypes.c_void_p]),
+    "mvd_sweep_reduce_workspace_bytes": (_sz, [_i] * 5),
+    "mvd_sweep_reduce_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _i] + [ctypes.c_float] * 4 + [_i] * 8
+                             + [_pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
     "mvd_resize_order1_f32": (_i, [_c_float_p, _c_float_p, ctypes.c_longlong, _i, _i, _i, _i, ctypes.c_void_p]),
     "mvd_nchw_to_nhwc_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),
     "mvd_nhwc_to_nchw_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_void_p]),

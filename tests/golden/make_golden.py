@@ -418,7 +418,71 @@ def g10():
     save("g10_grads", **out)
 
 
+def g11():
+    """Other sweep consumers.  The reference's CVP-MVSNet / Vis-MVSNet sweep code is CUDA-only only
+    through hard `.cuda()` calls on freshly made constants; with Tensor.cuda patched to the identity the very same functions
+    run on CPU: proj_cost (cvp_mvsnet_components.py:375-456) and get_homographies + homography_warping +
+    groupwise_correlation as SingleStage.build_cost_volume chains them (vis_mvsnet_singlestage.py:86-122,242)."""
+    import types
+    from _ref_loader import _load
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    cvp = _load("rmvd.models.blocks.cvp_mvsnet_components", "rmvd/models/blocks/cvp_mvsnet_components.py")
+    bu = ref.blocks_utils
+    out = {}
+    # ---- cvp: B=1, C=16, 12x18, D=6, 2 sources; per-pixel hypotheses and per-plane hypotheses
+    rng = np.random.default_rng(1300)
+    B, C, h, w, D, V = 1, 16, 12, 18, 6, 2
+    K = gc.synthetic_intrinsics(h * 4, w * 4)
+    K[:2] *= 0.25
+    ref_f = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    src_f = [rng.standard_normal((B, C, h, w)).astype(np.float32) for _ in range(V)]
+    ref_ex = np.eye(4, dtype=np.float32)[None]
+    src_ex = np.stack([gc.synthetic_pose(rng, 0.08, 0.2) for _ in range(V)])[None]          # (B,V,4,4)
+    ref_in = K[None]
+    src_in = np.stack([K * np.array([[1.05], [0.97], [1.0]], np.float32), K])[None]          # (B,V,3,3)
+    planes = np.linspace(0.6, 6.0, D, dtype=np.float32)
+    hyp_pp = (planes[None, :, None, None] * (1.0 + 0.15 * rng.uniform(-1, 1, (B, D, h, w)))).astype(np.float32)
+    hyp_pl = np.broadcast_to(planes[None, :, None, None], (B, D, h, w)).astype(np.float32).copy()
+    settings = types.SimpleNamespace(nsrc=V, mode="test")
+    for name, hyp in (("pp", hyp_pp), ("pl", hyp_pl)):
+        cv = cvp.proj_cost(settings, t(ref_f.copy()), [[t(f)] for f in src_f], 0, t(ref_in), t(src_in), t(ref_ex), t(src_ex), t(hyp))
+        out[f"cvp_{name}_cost"] = cv.numpy()
+    out.update(cvp_ref=ref_f, cvp_src0=src_f[0], cvp_src1=src_f[1], cvp_ref_in=ref_in, cvp_src_in=src_in, cvp_ref_ex=ref_ex,
+               cvp_src_ex=src_ex, cvp_hyp_pp=hyp_pp, cvp_hyp_pl=hyp_pl)
+    # ---- vis: B=2, C=32 (8 groups), 12x20, D=5, 2 sources; scalar and per-pixel depth_start / depth_interval
+    rng = np.random.default_rng(1310)
+    B, C, h, w, D, V = 2, 32, 12, 20, 5, 2
+    Kv = gc.synthetic_intrinsics(h, w)
+
+    def cam(T):
+        c = np.zeros((2, 4, 4), np.float32)
+        c[0] = T
+        c[1, :3, :3] = Kv
+        c[1, 3, 3] = 1
+        return c
+
+    ref_cam = np.stack([cam(np.eye(4, dtype=np.float32)), cam(gc.synthetic_pose(rng, 0.02, 0.05))])
+    srcs_cam = [np.stack([cam(gc.synthetic_pose(rng, 0.08, 0.2)) for _ in range(B)]) for _ in range(V)]
+    ref_f = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    srcs_f = [rng.standard_normal((B, C, h, w)).astype(np.float32) for _ in range(V)]
+    ds_s = np.full((B, 1, 1, 1), 0.8, np.float32)
+    di_s = np.full((B, 1, 1, 1), 0.9, np.float32)
+    ds_p = (0.8 + 0.3 * rng.uniform(0, 1, (B, 1, h, w))).astype(np.float32)
+    di_p = (0.9 + 0.2 * rng.uniform(0, 1, (B, 1, h, w))).astype(np.float32)
+    for name, ds, di in (("s", ds_s, di_s), ("p", ds_p, di_p)):
+        for v in range(V):
+            Hs = bu.get_homographies(t(ref_cam), t(srcs_cam[v]), D, t(ds), t(di))
+            src_nd = t(srcs_f[v]).unsqueeze(1).repeat(1, D, 1, 1, 1).view(-1, C, h, w)
+            Hs_flat = Hs.view(-1, *Hs.size()[2:])
+            warped = bu.homography_warping(src_nd, Hs_flat).view(-1, D, C, h, w).transpose(1, 2)
+            ref_ncdhw = t(ref_f).unsqueeze(2).expand(-1, -1, D, -1, -1)
+            out[f"vis_{name}_cost{v}"] = bu.groupwise_correlation(ref_ncdhw, warped, 8, 1).numpy()
+    out.update(vis_ref=ref_f, vis_src0=srcs_f[0], vis_src1=srcs_f[1], vis_ref_cam=ref_cam, vis_src_cam0=srcs_cam[0],
+               vis_src_cam1=srcs_cam[1], vis_ds_s=ds_s, vis_di_s=di_s, vis_ds_p=ds_p, vis_di_p=di_p)
+    save("g11_sweep_modes", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for g in which:
         globals()[g]()

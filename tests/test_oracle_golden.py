@@ -327,3 +327,28 @@ def test_g10_fusion_backward():
         np.testing.assert_allclose(dcorrs[v] + cv.grad.numpy(), g[f"k2_dcorr{v}"], atol=2e-4, rtol=1e-3)
     for k, prm in sd.items():
         np.testing.assert_allclose(prm.grad.numpy(), g["k2_d" + k], atol=5e-4, rtol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# other sweep consumers (g11): CVP-MVSNet proj_cost and Vis-MVSNet group-wise correlation, made by
+# running the reference's (CUDA-only) functions on CPU with Tensor.cuda patched to the identity (make_golden.py::g11)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["pp", "pl"])
+def test_g11_cvp_proj_cost(name):
+    g = load_golden("g11_sweep_modes")
+    got = O.cvp_proj_cost(g["cvp_ref"], [g["cvp_src0"], g["cvp_src1"]], g["cvp_ref_in"], g["cvp_src_in"], g["cvp_ref_ex"],
+                          g["cvp_src_ex"], g[f"cvp_hyp_{name}"], alias_bug=True)
+    np.testing.assert_allclose(got, g[f"cvp_{name}_cost"], atol=ATOL, rtol=RTOL)
+    fixed = O.cvp_proj_cost(g["cvp_ref"], [g["cvp_src0"], g["cvp_src1"]], g["cvp_ref_in"], g["cvp_src_in"], g["cvp_ref_ex"],
+                            g["cvp_src_ex"], g[f"cvp_hyp_{name}"], alias_bug=False)
+    assert np.abs(fixed - g[f"cvp_{name}_cost"]).max() > 0.1  # the aliasing is not a rounding matter
+    assert fixed.min() > -1e-4                                 # ... and the un-aliased form is a true variance
+
+
+@pytest.mark.parametrize("name", ["s", "p"])
+def test_g11_vis_cost_volumes(name):
+    g = load_golden("g11_sweep_modes")
+    got = O.vis_cost_volumes(g["vis_ref"], g["vis_ref_cam"], [g["vis_src0"], g["vis_src1"]], [g["vis_src_cam0"], g["vis_src_cam1"]],
+                             5, g[f"vis_ds_{name}"], g[f"vis_di_{name}"], groups=8)
+    for v in range(2):
+        np.testing.assert_allclose(got[v], g[f"vis_{name}_cost{v}"], atol=ATOL, rtol=RTOL)
