@@ -852,7 +852,8 @@ static int launch_conv0_ksplit(const ConvParams& p0, hipStream_t st) {
         return MVD_ERR_INVALID_ARG;
     }
     if (nblk < march_min_blocks()) {  // too few workgroups to fill 256 CUs: shorter chunks, then the other kernels
-        if constexpr (DZ > 8) return launch_conv0_ksplit<8>(p0, st);
+        if constexpr (DZ > 16) return launch_conv0_ksplit<16>(p0, st);
+        else if constexpr (DZ > 8) return launch_conv0_ksplit<8>(p0, st);
         return -1;
     }
     auto kern = conv0_ksplit_kernel<DZ>;
@@ -1420,7 +1421,11 @@ static int dispatch_cout(const ConvParams& p, hipStream_t st) {
         if (p.Cout == 8) {
             if constexpr (CIN == 32)
                 if (!old && !p.skip && !exp_env("MVD_K4_NOKSPLIT")) {  // conv0: two waves per row, split over the input channels
-                    const int rc = launch_conv0_ksplit<16>(p, st);
+                    int rc = -1;
+                    const char* dz = exp_env("MVD_K4_CONV0_DZ");  // experiments library: planes per workgroup march
+                    if (dz && atoi(dz) == 32) rc = launch_conv0_ksplit<32>(p, st);
+                    else if (dz && atoi(dz) == 64) rc = launch_conv0_ksplit<64>(p, st);
+                    else rc = launch_conv0_ksplit<16>(p, st);
                     if (rc >= 0) return rc;
                 }
             if constexpr (CIN <= 32)

@@ -11,7 +11,10 @@ import robustmvd_amd as R
 CONFIGS = {1: (448, 640, 2, 128), 2: (768, 1152, 4, 256), 3: (896, 1216, 4, 256), 4: (704, 1280, 6, 512)}
 ap = argparse.ArgumentParser(); ap.add_argument("--config", type=int, default=2); ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--only", default="")
+ap.add_argument("--exp", action="store_true", help="route through lib_exp/libmvd_hip_exp.so (MVD_K4_* selectors apply)")
 args = ap.parse_args()
+if args.exp:
+    L.use_experiments_library().__enter__()
 H, W, V, D = CONFIGS[args.config]
 h, w = H // 4, W // 4
 dev = torch.device("cuda:0")
