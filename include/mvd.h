@@ -90,6 +90,18 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
                        float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
                        mvd_stream_t stream);
 
+/* K1 with the block's other options (planesweep_corr.py:371-394, 465-487): sampling inverse depths shared (1,S), per batch
+ * element (N,S) or PER KEY PIXEL (N,S,h,w); `corr_scale` multiplies the dot products: 1/sqrt(C) for normalize="dim" (what
+ * mvd_sweep_corr_f32 uses), 1 for normalize=False / "before" (the caller normalises the features beforehand). */
+#define MVD_INVDEPTH_SHARED 0
+#define MVD_INVDEPTH_BATCHED 1
+#define MVD_INVDEPTH_PER_PIXEL 2
+int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
+                          const float* const* K_src, const float* const* T_src2key, const float* invdepths,
+                          int invdepth_mode, float corr_scale, int N, int C, int h, int w, int hs, int ws, int S, int V,
+                          float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
+                          mvd_stream_t stream);
+
 /* K2 — replaces the view-weighting arithmetic of LearnedFusion.forward
  *   rmvd/models/blocks/learned_fusion.py:32-48 (softmax over views + 1e-9, mask-weighted mean, fused mask).
  * The per-view score maps (conv3x3+ReLU+conv1x1, :13-17,:28-30) are 2-D convolutions that stay on
@@ -245,11 +257,12 @@ int mvd_warp_variance_backward_f32(const float* key_feat, const float* const* sr
                                    size_t workspace_bytes, mvd_stream_t stream);
 
 /* VJP of mvd_sweep_corr_f32 (masks are constants).  feat_key, grad_key (N,h,w,C) channel-last; feat_src[v], grad_src[v]
- * (N,hs+3,ws+3,C) zero-bordered channel-last; grad_corr[v] (N,S,h,w).  C in {64,128,192,256}. */
+ * (N,hs+3,ws+3,C) zero-bordered channel-last; grad_corr[v] (N,S,h,w).  C in {64,128,192,256}.  invdepth_mode / corr_scale as
+ * in mvd_sweep_corr_ex_f32. */
 int mvd_sweep_corr_backward_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
                                 const float* const* K_src, const float* const* T_src2key, const float* invdepths,
-                                int invdepth_batched, const float* const* grad_corr, int N, int C, int h, int w, int hs, int ws,
-                                int S, int V, float* grad_key, float* const* grad_src, mvd_stream_t stream);
+                                int invdepth_mode, float corr_scale, const float* const* grad_corr, int N, int C, int h, int w,
+                                int hs, int ws, int S, int V, float* grad_key, float* const* grad_src, mvd_stream_t stream);
 
 /* VJP of mvd_fuse_views_f32 w.r.t. corr[v] (N,S,h,w) and score[v] (N,1,h,w); masks and the fused mask are constants. */
 int mvd_fuse_views_backward_f32(const float* const* corr, const float* const* mask, const float* const* score,

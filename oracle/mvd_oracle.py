@@ -117,7 +117,8 @@ def sweep_grids(co, invdepths):
     """A2+A3. us_from_ds / vs_from_ds with replace_nonfinite (planesweep_corr.py:333-349) and the
     visibility mask of get_plane_sweep_sampling_points (:489-512).
     invdepths (N,S) -> us, vs (N,S,h,w) float32; visible (N,S,h,w) bool."""
-    ds = np.asarray(invdepths, F32)[:, :, None, None]
+    ds = np.asarray(invdepths, F32)
+    ds = ds[:, :, None, None] if ds.ndim == 2 else ds  # (N,S) or per key pixel (N,S,h,w) (planesweep_corr.py:465-487)
     u_inf, v_inf, k_inf = (co[n][:, None] for n in ("u_inf", "v_inf", "k_inf"))
     m_u, m_v, m_k = (co[n][:, None, None, None] for n in ("m_u", "m_v", "m_k"))
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
@@ -140,7 +141,7 @@ def sweep_grids(co, invdepths):
     return us.astype(F32), vs.astype(F32), visible
 
 
-def sweep_corr_view(feat_key, feat_src, us, vs, visible):
+def sweep_corr_view(feat_key, feat_src, us, vs, visible, normalize="dim"):
     """A4. TorchCorr.forward (normalize="dim", zeros padding), planesweep_corr.py:152-195 with
     warp() :82-104.  The reference forms the all-pairs matrix and interpolates it; this is the
     equivalent warp-then-dot form (SURVEY.md 8c 'verified equivalence').
@@ -150,7 +151,10 @@ def sweep_corr_view(feat_key, feat_src, us, vs, visible):
     S = us.shape[1]
     corr = np.zeros((N, S, h, w), F32)
     mask = np.zeros((N, S, h, w), F32)
-    inv_sqrt_c = F32(1.0) / np.sqrt(F32(C))
+    inv_sqrt_c = F32(1.0) / np.sqrt(F32(C)) if normalize == "dim" else F32(1.0)
+    if normalize and normalize != "dim":  # True / "before": x / (|x| + 1e-9) along C (planesweep_corr.py:8-10,165-167)
+        feat_key = (feat_key / (np.linalg.norm(feat_key, axis=1, keepdims=True) + F32(1e-9))).astype(F32)
+        feat_src = (feat_src / (np.linalg.norm(feat_src, axis=1, keepdims=True) + F32(1e-9))).astype(F32)
     for n in range(N):
         for s in range(S):
             gx = F32(2.0) * us[n, s] / F32(ws) - F32(1.0)  # warp(): :87-88
@@ -173,7 +177,7 @@ def sweep_corr_view(feat_key, feat_src, us, vs, visible):
 
 def planesweep_correlation(feat_key, intrinsics_key, feat_sources, source_to_key_transforms,
                            intrinsics_sources=None, num_sampling_points=None, min_depth=None, max_depth=None,
-                           sampling_invdepths=None, sampling_type="linear_invdepth"):
+                           sampling_invdepths=None, sampling_type="linear_invdepth", normalize="dim"):
     """A5. PlanesweepCorrelation.forward, planesweep_corr.py:396-427.  Same arguments, numpy in/out.
     Returns (corrs[V], masks[V], sampling_invdepths (N,S,1,1))."""
     N, C, h, w = feat_key.shape
@@ -186,16 +190,22 @@ def planesweep_correlation(feat_key, intrinsics_key, feat_sources, source_to_key
     else:
         assert num_sampling_points is None and sampling_invdepths is not None
         inv = np.asarray(sampling_invdepths, F32)
-    inv = inv.reshape(inv.shape[0], inv.shape[1])
-    inv_n = np.broadcast_to(inv, (N, inv.shape[1]))
+    per_pixel = inv.ndim == 4 and (inv.shape[2] > 1 or inv.shape[3] > 1)
+    if per_pixel:
+        inv_n = np.broadcast_to(inv, (N, inv.shape[1], h, w))
+        inv_ret = inv
+    else:
+        inv = inv.reshape(inv.shape[0], inv.shape[1])
+        inv_n = np.broadcast_to(inv, (N, inv.shape[1]))
+        inv_ret = inv[:, :, None, None]
     corrs, masks = [], []
     for fs, T, Ks in zip(feat_sources, source_to_key_transforms, intrinsics_sources):
         co = epipolar_coeffs(intrinsics_key, Ks, T, h, w, fs.shape[2], fs.shape[3])
         us, vs, vis = sweep_grids(co, inv_n)
-        c, m = sweep_corr_view(feat_key, fs, us, vs, vis)
+        c, m = sweep_corr_view(feat_key, fs, us, vs, vis, normalize)
         corrs.append(c)
         masks.append(m)
-    return corrs, masks, inv[:, :, None, None]
+    return corrs, masks, inv_ret
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0):

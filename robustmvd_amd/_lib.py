@@ -25,6 +25,7 @@ DECONV3D_STRIDE2 = 2
 LAYOUT_NCHW = 0
 LAYOUT_NHWC = 1
 LAYOUT_NHWC_BORDER = 2
+INVDEPTH_SHARED, INVDEPTH_BATCHED, INVDEPTH_PER_PIXEL = 0, 1, 2
 REDUCE_VARIANCE = 0
 REDUCE_VARIANCE_KEYSQ = 1
 REDUCE_GROUPCORR = 2
@@ -41,6 +42,8 @@ SIGNATURES = {
     "mvd_sweep_corr_workspace_bytes": (_sz, [_i] * 7),
     "mvd_sweep_corr_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i] + [_i] * 8
                            + [_pp, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_sweep_corr_ex_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, ctypes.c_float] + [_i] * 8
+                              + [_pp, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
     "mvd_fuse_views_f32": (_i, [_pp, _pp, _pp, _i, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "mvd_warp_variance_workspace_bytes": (_sz, [_i] * 5),
     "mvd_warp_variance_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p] + [_i] * 6
@@ -68,7 +71,7 @@ SIGNATURES = {
     "mvd_warp_variance_backward_workspace_bytes": (_sz, [_i]),
     "mvd_warp_variance_backward_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p, _c_float_p] + [_i] * 6
                                        + [_c_float_p, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
-    "mvd_sweep_corr_backward_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, _pp] + [_i] * 8
+    "mvd_sweep_corr_backward_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, ctypes.c_float, _pp] + [_i] * 8
                                     + [_c_float_p, _pp, ctypes.c_void_p]),
     "mvd_fuse_views_backward_f32": (_i, [_pp, _pp, _pp, _c_float_p] + [_i] * 5 + [_pp, _pp, ctypes.c_void_p]),
     "mvd_sweep_reduce_workspace_bytes": (_sz, [_i] * 5),

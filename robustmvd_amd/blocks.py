@@ -44,9 +44,16 @@ class PlanesweepCorrelation(nn.Module):
     Stateless across calls (the reference keeps per-call state on self and is not re-entrant)."""
 
     def __init__(self, warp_only=False, normalize="dim"):
+        """normalize (TorchCorr, planesweep_corr.py:142-189): "dim" divides the dot products by sqrt(C) (what robust_mvd
+        uses); True / "before" L2-normalises both feature maps along C first (x / (|x| + 1e-9), :8-10); False leaves
+        the raw dot products.  warp_only=True (WarpOnlyCorr, :106-139: returns the warped source FEATURES instead of
+        correlations) is used by no model of the reference and is not built."""
         super().__init__()
-        if warp_only or normalize != "dim":
-            raise NotImplementedError("only the configuration robust_mvd uses (TorchCorr, normalize='dim') is built")
+        if warp_only:
+            raise NotImplementedError("warp_only=True (WarpOnlyCorr) is used by no registered model and is not built")
+        if normalize not in ("dim", "before", True, False):
+            raise ValueError(f"normalize={normalize!r}: expected 'dim', 'before', True or False")
+        self.normalize = normalize
         self._invdepth_cache = {}  # (num, min, max, type, device) -> device tensor: constants of the model, uploaded once
 
     def warm(self, num_sampling_points, min_depth, max_depth, sampling_type, device):
@@ -91,12 +98,21 @@ class PlanesweepCorrelation(nn.Module):
         elif num_sampling_points is not None or min_depth is not None or max_depth is not None or sampling_invdepths is None:
             raise ValueError("give either (num_sampling_points, min_depth, max_depth) or sampling_invdepths")
         inv = sampling_invdepths.to(feat_key.device)
-        if inv.dim() < 2:
-            raise ValueError("sampling_invdepths needs at least 2 dims (N, S)")
-        if inv.dim() > 2:
-            if any(s != 1 for s in inv.shape[2:]):
-                raise NotImplementedError("per-pixel sampling_invdepths (N,S,H,W) are not supported by the engine")
+        if inv.dim() < 2 or inv.dim() > 4:
+            raise ValueError("sampling_invdepths must be (N, S), (N, S, H) or (N, S, H, W)")
+        while inv.dim() < 4:  # planesweep_corr.py:484-485
+            inv = inv.unsqueeze(-1)
+        inv_out = inv
+        if inv.shape[2] == 1 and inv.shape[3] == 1:
             inv = inv.reshape(inv.shape[0], inv.shape[1])
+        else:  # per key pixel: (N,S,H,1) or (N,S,H,W), batch broadcast like the reference's arithmetic would
+            inv = inv.expand(feat_key.shape[0], inv.shape[1], feat_key.shape[2], feat_key.shape[3]).contiguous()
+        corr_scale = None  # 1/sqrt(C)
+        if self.normalize != "dim":
+            corr_scale = 1.0
+            if self.normalize:  # True / "before": x / (|x|_2 + 1e-9) along the channels (planesweep_corr.py:8-10,165-167)
+                nrm = lambda x: x / (torch.linalg.norm(x, dim=1, keepdim=True) + 1e-9)
+                feat_key, feat_sources = nrm(feat_key), [nrm(f) for f in feat_sources]
         # sources may differ in size: one launch per group of equal (hs, ws)
         corrs = [None] * len(feat_sources)
         masks = [None] * len(feat_sources)
@@ -105,10 +121,10 @@ class PlanesweepCorrelation(nn.Module):
             groups.setdefault(tuple(f.shape[-2:]), []).append(i)
         for idxs in groups.values():
             c, m = sweep(feat_key, [feat_sources[i] for i in idxs], intrinsics_key,
-                         [intrinsics_sources[i] for i in idxs], [source_to_key_transforms[i] for i in idxs], inv)
+                         [intrinsics_sources[i] for i in idxs], [source_to_key_transforms[i] for i in idxs], inv, corr_scale)
             for i, ci, mi in zip(idxs, c, m):
                 corrs[i], masks[i] = ci, mi
-        return corrs, masks, inv[:, :, None, None]
+        return corrs, masks, inv_out
 
 
 class LearnedFusion(nn.Module):

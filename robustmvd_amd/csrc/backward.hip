@@ -159,6 +159,8 @@ struct SweepBwdParams {
     const float* K_key;  // (N,3,3)
     const float* invd;
     int invd_stride;
+    int invd_per_pixel;
+    float corr_scale;
     int N, h, w, hs, ws, S, V;
 };
 
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(256) sweep_corr_backward_kernel(SweepBwdParams
     if (wid >= (long long)p.N * p.h * p.w) return;  // wave-uniform
     const int x = (int)(wid % p.w), y = (int)((wid / p.w) % p.h), n = (int)(wid / ((long long)p.w * p.h));
     const int h = p.h, w = p.w, hs = p.hs, ws = p.ws, S = p.S, W2 = ws + 3;
-    const float inv_sqrt_c = 1.0f / sqrtf((float)C);
+    const float inv_sqrt_c = p.corr_scale;
     const float fws = (float)ws, fhs = (float)hs, xc = (float)x + 0.5f, yc = (float)y + 0.5f;
     const float* __restrict__ invd = p.invd + (size_t)n * p.invd_stride;
     float kf[NJ], gk[NJ];
@@ -200,7 +202,8 @@ __global__ void __launch_bounds__(256) sweep_corr_backward_kernel(SweepBwdParams
         for (int s0 = 0; s0 < S; s0 += 64) {
             const int s = s0 + lane;
             const bool live = s < S;
-            const float ds = invd[live ? s : S - 1];
+            const int sc = live ? s : S - 1;
+            const float ds = p.invd_per_pixel ? p.invd[(((size_t)n * S + sc) * h + y) * w + x] : invd[sc];
             const float den = k_inf + E.m * ds;
             const float us = fix_nonfinite((u_inf + E.e * ds) / den), vs = fix_nonfinite((v_inf + E.i * ds) / den);
             const float zs = 1.0f / ds;
@@ -348,9 +351,10 @@ int mvd_warp_variance_backward_f32(const float* key_feat, const float* const* sr
 
 int mvd_sweep_corr_backward_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
                                 const float* const* K_src, const float* const* T_src2key, const float* invdepths,
-                                int invdepth_batched, const float* const* grad_corr, int N, int C, int h, int w, int hs, int ws,
-                                int S, int V, float* grad_key, float* const* grad_src, mvd_stream_t stream) {
+                                int invdepth_mode, float corr_scale, const float* const* grad_corr, int N, int C, int h, int w,
+                                int hs, int ws, int S, int V, float* grad_key, float* const* grad_src, mvd_stream_t stream) {
     using namespace mvd;
+    MVD_REQUIRE(invdepth_mode >= MVD_INVDEPTH_SHARED && invdepth_mode <= MVD_INVDEPTH_PER_PIXEL, "sweep_corr_backward: invdepth_mode %d", invdepth_mode);
     MVD_REQUIRE(feat_key && feat_src && K_key && K_src && T_src2key && invdepths && grad_corr && grad_key && grad_src,
                 "sweep_corr_backward: NULL argument");
     MVD_REQUIRE(N > 0 && h > 0 && w > 0 && hs > 0 && ws > 0 && S > 0 && V >= 1 && V <= MVD_MAX_VIEWS, "sweep_corr_backward: bad dimensions");
@@ -364,7 +368,10 @@ int mvd_sweep_corr_backward_f32(const float* feat_key, const float* const* feat_
         p.gsrc.p[v] = grad_src[v];
         if (hipMemsetAsync(grad_src[v], 0, slot, st) != hipSuccess) return launch_status("sweep_corr_backward: memset");
     }
-    p.key = feat_key; p.gkey = grad_key; p.K_key = K_key; p.invd = invdepths; p.invd_stride = invdepth_batched ? S : 0;
+    p.key = feat_key; p.gkey = grad_key; p.K_key = K_key; p.invd = invdepths;
+    p.invd_stride = invdepth_mode == MVD_INVDEPTH_BATCHED ? S : 0;
+    p.invd_per_pixel = invdepth_mode == MVD_INVDEPTH_PER_PIXEL;
+    p.corr_scale = corr_scale;
     p.N = N; p.h = h; p.w = w; p.hs = hs; p.ws = ws; p.S = S; p.V = V;
     const long long nwave = (long long)N * h * w, nblk = (nwave + 3) / 4;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "sweep_corr_backward: grid too large");

@@ -29,8 +29,10 @@ struct SweepParams {
     ViewOutPtrs mask;    // V x (N,S,h,w)
     const float* key;    // (N,h,w,C) channel-last key features
     const float* K_key;  // (N,3,3)
-    const float* invd;   // (N,S) or (1,S)
-    int invd_stride;     // S if batched else 0
+    const float* invd;   // (1,S), (N,S) or per key pixel (N,S,h,w)
+    int invd_stride;     // S if batched else 0 (ignored when per pixel)
+    int invd_per_pixel;  // planesweep_corr.py:465-487 accepts (N,S), (N,S,H) and (N,S,H,W) sampling inverse depths
+    float corr_scale;    // 1/sqrt(C) for normalize="dim" (planesweep_corr.py:186), 1 otherwise
     int N, h, w, hs, ws, S, V;
 };
 
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
     const Epi E = epipolar(p.K_key + n * 9, p.K_src.p[v] + n * 9, p.T.p[v] + n * 16, h, w, hs, ws);
     const float* __restrict__ src = p.src.p[v] + (size_t)n * (hs + 3) * W2 * C + lane * NJ;
     const float* __restrict__ invd = p.invd + (size_t)n * p.invd_stride;
-    const float inv_sqrt_c = 1.0f / sqrtf((float)C);
+    const float inv_sqrt_c = p.corr_scale;
     const float fws = (float)ws, fhs = (float)hs;
     const float yc = (float)y + 0.5f;
 
@@ -158,7 +160,8 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
             // ---- geometry of plane s0 + lane ----
             const int s = s0 + lane;
             const bool live = s < S;
-            const float ds = invd[live ? s : S - 1];
+            const int sc = live ? s : S - 1;
+            const float ds = p.invd_per_pixel ? p.invd[(((size_t)n * S + sc) * h + y) * w + x] : invd[sc];
             const float den = k_inf + E.m * ds;
             const float us = replace_nonfinite((u_inf + E.e * ds) / den);  // :334
             const float vs = replace_nonfinite((v_inf + E.i * ds) / den);  // :343
@@ -252,6 +255,18 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
                        int invdepth_batched, int N, int C, int h, int w, int hs, int ws, int S, int V,
                        float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
                        mvd_stream_t stream) {
+    return mvd_sweep_corr_ex_f32(feat_key, feat_src, K_key, K_src, T_src2key, invdepths,
+                                 invdepth_batched ? MVD_INVDEPTH_BATCHED : MVD_INVDEPTH_SHARED, 1.0f / sqrtf((float)(C > 0 ? C : 1)), N,
+                                 C, h, w, hs, ws, S, V, corr_out, mask_out, workspace, workspace_bytes, stream);
+}
+
+int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
+                          const float* const* K_src, const float* const* T_src2key, const float* invdepths,
+                          int invdepth_mode, float corr_scale, int N, int C, int h, int w, int hs, int ws, int S, int V,
+                          float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
+                          mvd_stream_t stream) {
+    MVD_REQUIRE(invdepth_mode == MVD_INVDEPTH_SHARED || invdepth_mode == MVD_INVDEPTH_BATCHED || invdepth_mode == MVD_INVDEPTH_PER_PIXEL,
+                "sweep_corr: invdepth_mode %d", invdepth_mode);
     MVD_REQUIRE(feat_key && feat_src && K_key && K_src && T_src2key && invdepths && corr_out && mask_out,
                 "sweep_corr: NULL argument");
     MVD_REQUIRE(N > 0 && h > 0 && w > 0 && hs > 0 && ws > 0 && S > 0, "sweep_corr: non-positive dimension");
@@ -286,7 +301,9 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
     }
     p.K_key = K_key;
     p.invd = invdepths;
-    p.invd_stride = invdepth_batched ? S : 0;
+    p.invd_stride = invdepth_mode == MVD_INVDEPTH_BATCHED ? S : 0;
+    p.invd_per_pixel = invdepth_mode == MVD_INVDEPTH_PER_PIXEL;
+    p.corr_scale = corr_scale;
     p.N = N; p.h = h; p.w = w; p.hs = hs; p.ws = ws; p.S = S; p.V = V;
     dim3 grid((unsigned)((w + mvd::SWEEP_PX - 1) / mvd::SWEEP_PX), (unsigned)h, (unsigned)(N * V));
     mvd::timing_begin(st);

@@ -49,10 +49,20 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+def _invdepth_mode(inv, N, h, w):
+    """(1,S) shared, (N,S) per batch element, or (N,S,h,w) per key pixel (planesweep_corr.py:465-487)."""
+    if inv.dim() == 2 and inv.shape[0] in (1, N):
+        return L.INVDEPTH_BATCHED if (inv.shape[0] == N and N > 1) else L.INVDEPTH_SHARED
+    if inv.dim() == 4 and tuple(inv.shape[0:1] + inv.shape[2:]) == (N, h, w):
+        return L.INVDEPTH_PER_PIXEL
+    raise ValueError(f"sampling_invdepths must be (1 or N, S) or (N, S, h, w), got {tuple(inv.shape)}")
+
+
 @inference_only
-def sweep_corr(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths):
+def sweep_corr(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths, corr_scale=None):
     """K1. feat_key (N,C,h,w); feat_sources V x (N,C,hs,ws); K_* relative intrinsics (N,3,3);
-    T_src2key V x (N,4,4); invdepths (1 or N, S).  Returns (corrs[V], masks[V]) each (N,S,h,w)."""
+    T_src2key V x (N,4,4); invdepths (1 or N, S) or per key pixel (N,S,h,w); corr_scale: multiplier of the dot products,
+    default 1/sqrt(C) (normalize="dim").  Returns (corrs[V], masks[V]) each (N,S,h,w)."""
     lib = L.load()
     fk = L.as_f32(feat_key, "feat_key")
     if fk.dim() != 4:
@@ -67,9 +77,9 @@ def sweep_corr(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths):
     Ks = [L.as_f32(k, f"intrinsics_sources[{i}]", (N, 3, 3), dev) for i, k in enumerate(_views(K_sources, "intrinsics_sources", V))]
     Ts = [L.as_f32(t, f"source_to_key_transforms[{i}]", (N, 4, 4), dev) for i, t in enumerate(_views(T_src2key, "source_to_key_transforms", V))]
     inv = L.as_f32(invdepths, "sampling_invdepths", device=dev)
-    if inv.dim() != 2 or inv.shape[0] not in (1, N):
-        raise ValueError(f"sampling_invdepths must be (1 or N, S), got {tuple(inv.shape)}")
+    mode = _invdepth_mode(inv, N, h, w)
     S = inv.shape[1]
+    scale = float(corr_scale) if corr_scale is not None else 1.0 / float(C) ** 0.5
     if C % 64 != 0:
         raise ValueError(f"feature channels C={C} must be a multiple of 64")
     corrs = [torch.empty((N, S, h, w), dtype=torch.float32, device=dev) for _ in range(V)]
@@ -82,9 +92,9 @@ def sweep_corr(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths):
     a_c, k4 = L.ptr_array(corrs)
     a_m, k5 = L.ptr_array(masks)
     with torch.cuda.device(dev):
-        rc = lib.mvd_sweep_corr_f32(L.ptr(fk), a_src, L.ptr(Kk), a_K, a_T, L.ptr(inv), int(inv.shape[0] == N and N > 1),
-                                    N, C, h, w, hs, ws, S, V, a_c, a_m, L.ptr(wsp), wsb, L.stream_of(fk))
-    L.check(rc, "mvd_sweep_corr_f32")
+        rc = lib.mvd_sweep_corr_ex_f32(L.ptr(fk), a_src, L.ptr(Kk), a_K, a_T, L.ptr(inv), mode, scale,
+                                       N, C, h, w, hs, ws, S, V, a_c, a_m, L.ptr(wsp), wsb, L.stream_of(fk))
+    L.check(rc, "mvd_sweep_corr_ex_f32")
     return corrs, masks
 
 
@@ -507,12 +517,13 @@ def warp_variance_autograd(key_feat, src_feats, src_projs, key_proj_inv, depth_v
 
 class _SweepCorr(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, K_key, invdepths, n_views, feat_key, *rest):
+    def forward(ctx, K_key, invdepths, n_views, corr_scale, feat_key, *rest):
         V = n_views
         srcs, Ks, Ts = list(rest[:V]), list(rest[V:2 * V]), list(rest[2 * V:])
-        corrs, masks = sweep_corr(feat_key.detach(), [s.detach() for s in srcs], K_key, Ks, Ts, invdepths)
+        corrs, masks = sweep_corr(feat_key.detach(), [s.detach() for s in srcs], K_key, Ks, Ts, invdepths, corr_scale)
         ctx.save_for_backward(K_key, invdepths, feat_key, *srcs, *Ks, *Ts)
         ctx.n_views = V
+        ctx.corr_scale = corr_scale
         ctx.mark_non_differentiable(*masks)
         return tuple(corrs) + tuple(masks)
 
@@ -541,20 +552,21 @@ class _SweepCorr(torch.autograd.Function):
             a_gc, k4 = L.ptr_array(gc)
             a_gs, k5 = L.ptr_array(gs)
             invf = L.as_f32(inv, "invdepths", device=dev)
+            scale = float(ctx.corr_scale) if ctx.corr_scale is not None else 1.0 / float(C) ** 0.5
             with torch.cuda.device(dev):
                 rc = lib.mvd_sweep_corr_backward_f32(L.ptr(key), a_s, L.ptr(L.as_f32(Kk, "K_key", (N, 3, 3), dev)), a_K, a_T,
-                                                     L.ptr(invf), int(invf.shape[0] == N and N > 1), a_gc, N, C, h, w, hs, ws, S,
-                                                     V, L.ptr(gk), a_gs, L.stream_of(key))
+                                                     L.ptr(invf), _invdepth_mode(invf, N, h, w), scale, a_gc, N, C, h, w, hs, ws,
+                                                     S, V, L.ptr(gk), a_gs, L.stream_of(key))
             L.check(rc, "mvd_sweep_corr_backward_f32")
-            out = [None, None, None, gk.permute(0, 3, 1, 2).contiguous()] + [_interior_nchw(x, hs, ws) for x in gs] + [None] * (2 * V)
+            out = [None, None, None, None, gk.permute(0, 3, 1, 2).contiguous()] + [_interior_nchw(x, hs, ws) for x in gs] + [None] * (2 * V)
         return tuple(out)
 
 
-def sweep_corr_autograd(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths):
+def sweep_corr_autograd(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths, corr_scale=None):
     """Differentiable K1: returns (corrs[V], masks[V]); gradients to feat_key and feat_sources."""
     srcs = _views(feat_sources, "feat_sources")
     V = len(srcs)
-    outs = _SweepCorr.apply(K_key, invdepths, V, feat_key, *srcs, *_views(K_sources, "intrinsics_sources", V),
+    outs = _SweepCorr.apply(K_key, invdepths, V, corr_scale, feat_key, *srcs, *_views(K_sources, "intrinsics_sources", V),
                             *_views(T_src2key, "source_to_key_transforms", V))
     return list(outs[:V]), list(outs[V:])
 

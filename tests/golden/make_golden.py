@@ -482,7 +482,34 @@ def g11():
     save("g11_sweep_modes", **out)
 
 
+def g12():
+    """The other options of the PlanesweepCorrelation block (planesweep_corr.py:371-394, 465-487): normalize=False and
+    normalize="before", and sampling inverse depths per key pixel (N,S,H,W).  C = 64, 12x18, S = 8, 2 sources."""
+    K_px, T_sd = sample_data_calib()
+    K_rel = (K_px / np.array([[1280.0] * 3, [720.0] * 3, [1.0] * 3], np.float32))[None]
+    fk = gc.rng_array(1401, (1, 64, 12, 18))
+    fs = [gc.rng_array(1402 + i, (1, 64, 12, 18)) for i in range(2)]
+    Ts = [T_sd[0][None], T_sd[3][None]]
+    out = {"K": K_rel, "T0": Ts[0], "T1": Ts[1]}
+    rng = np.random.default_rng(1410)
+    base = ref.planesweep_corr.compute_sampling_invdepths(0.4, 1000.0, 8).numpy()            # (1,8)
+    inv_pp = (base[:, :, None, None] * (1.0 + 0.2 * rng.uniform(-1, 1, (1, 8, 12, 18)))).astype(np.float32)
+    out["invdepths_pp"] = inv_pp
+    for name, norm, inv in (("none", False, None), ("before", "before", None), ("pp", "dim", inv_pp)):
+        blk = ref.planesweep_corr.PlanesweepCorrelation(normalize=norm)
+        kw = dict(feat_key=t(fk), intrinsics_key=t(K_rel), feat_sources=[t(f) for f in fs], source_to_key_transforms=[t(T) for T in Ts])
+        if inv is None:
+            kw.update(num_sampling_points=8, min_depth=0.4, max_depth=1000.0)
+        else:
+            kw.update(sampling_invdepths=t(inv))
+        corrs, masks, invd = blk(**kw)
+        for v in range(2):
+            out[f"{name}_corr{v}"] = corrs[v].numpy()
+            out[f"{name}_mask{v}"] = np.packbits(masks[v].numpy().astype(np.uint8).ravel())
+    save("g12_sweep_options", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for g in which:
         globals()[g]()

@@ -341,3 +341,26 @@ def test_mvsnet_end_to_end_golden(dev):
                         depth_range=(np.float32(0.5), np.float32(10.0)))
     np.testing.assert_allclose(pred["depth"][None], g["depth"], rtol=1e-3)   # Path B depth rtol 1e-3
     np.testing.assert_allclose(pred["depth_uncertainty"][None], g["depth_uncertainty"], atol=2e-3)
+
+
+@pytest.mark.parametrize("name,norm", [("none", False), ("before", "before"), ("pp", "dim")])
+def test_sweep_block_options_golden(name, norm, dev):
+    """PlanesweepCorrelation(normalize=False / "before") and per-key-pixel sampling inverse depths (N,S,H,W) against
+    the reference block's outputs (g12); warp_only stays unbuilt (used by no model of the reference)."""
+    import robustmvd_amd as R
+    g = load_golden("g12_sweep_options")
+    fk = T(gc.rng_array(1401, (1, 64, 12, 18)), dev)
+    fs = [T(gc.rng_array(1402 + i, (1, 64, 12, 18)), dev) for i in range(2)]
+    blk = R.PlanesweepCorrelation(normalize=norm)
+    kw = dict(sampling_invdepths=T(g["invdepths_pp"], dev)) if name == "pp" else dict(num_sampling_points=8, min_depth=0.4, max_depth=1000.0)
+    corrs, masks, inv = blk(fk, T(g["K"], dev), fs, [T(g["T0"], dev), T(g["T1"], dev)], **kw)
+    assert tuple(inv.shape) == ((1, 8, 12, 18) if name == "pp" else (1, 8, 1, 1))
+    for v in range(2):
+        ref_c = g[f"{name}_corr{v}"]
+        ref_m = unpack_mask(g[f"{name}_mask{v}"], ref_c.shape)
+        m = masks[v].cpu().numpy()
+        assert (m != ref_m).mean() <= 1e-3
+        ok = m == ref_m
+        np.testing.assert_allclose(corrs[v].cpu().numpy()[ok], ref_c[ok], atol=ATOL, rtol=RTOL)
+    with pytest.raises(NotImplementedError):
+        R.PlanesweepCorrelation(warp_only=True)

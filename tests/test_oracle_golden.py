@@ -352,3 +352,19 @@ def test_g11_vis_cost_volumes(name):
                              5, g[f"vis_ds_{name}"], g[f"vis_di_{name}"], groups=8)
     for v in range(2):
         np.testing.assert_allclose(got[v], g[f"vis_{name}_cost{v}"], atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("name,norm", [("none", False), ("before", "before"), ("pp", "dim")])
+def test_g12_sweep_block_options(name, norm):
+    """normalize=False / "before" and per-key-pixel sampling inverse depths (planesweep_corr.py:371-394, 465-487)"""
+    g = load_golden("g12_sweep_options")
+    fk = gc.rng_array(1401, (1, 64, 12, 18))
+    fs = [gc.rng_array(1402 + i, (1, 64, 12, 18)) for i in range(2)]
+    kw = dict(sampling_invdepths=g["invdepths_pp"]) if name == "pp" else dict(num_sampling_points=8, min_depth=0.4, max_depth=1000.0)
+    corrs, masks, _ = O.planesweep_correlation(fk, g["K"], fs, [g["T0"], g["T1"]], normalize=norm, **kw)
+    for v in range(2):
+        ref_c = g[f"{name}_corr{v}"]
+        ref_m = unpack_mask(g[f"{name}_mask{v}"], ref_c.shape)
+        assert (masks[v] != ref_m).mean() <= 1e-3
+        ok = masks[v] == ref_m
+        np.testing.assert_allclose(corrs[v][ok], ref_c[ok], atol=ATOL, rtol=RTOL)
