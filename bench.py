@@ -58,9 +58,9 @@ def build_mvsnet(D, dev, seed=0, half_features=False):
     return R.add_run_function(model.to(dev)), sd
 
 
-def build_robustmvd(dev, seed=0):
+def build_robustmvd(dev, seed=0, half_dispnet=False):
     import robustmvd_amd as R
-    model = R.RobustMVD().eval()
+    model = R.RobustMVD(half_dispnet=half_dispnet).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = gc.robustmvd_weights(shapes, seed)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -346,7 +346,17 @@ def main():
                                       "algorithmic_flops_per_launch": k1_flops, "algorithmic_bytes_per_launch": k1_bytes,
                                       "algorithmic_gbs": k1_bytes / (k1_ms * 1e-3) / 1e9, "avg_launch_ms": k1_ms,
                                       "launches_timed": args.steps, "pmc": k1_pmc}}
-        del ma, sa
+        del ma
+        torch.cuda.empty_cache()
+        # opt-in variant, NOT the fp32 drop-in: the DispNet's 2-D convolutions on the vendor library's fp16 kernels under
+        # autocast (SURVEY.md 8f rank 1 lists fp16 as a tuning lever of that row); sweep, fusion and heads stay fp32
+        mh, _ = build_robustmvd(dev, half_dispnet=True)
+        dth = timed_loop(mh, sa, args.steps, args.warmup, world, dev, None, cdev)
+        out["path_a_half_dispnet"] = {"model": "robust_mvd(half_dispnet=True)", "value": world * args.steps / dth,
+                                      "unit": "depth-maps/sec", "ms_per_step": dth / args.steps * 1e3,
+                                      "dtype": "f16 vendor convolutions (f32 accumulate) around an f32 sweep",
+                                      "note": "opt-in; inverse depth within 2e-2 of the fp32 model (tests/test_hip_configs.py)"}
+        del mh, sa
         torch.cuda.empty_cache()
 
 

@@ -323,8 +323,8 @@ class _ConvLeaky(nn.Sequential):
             y = F.conv_transpose2d(x, c.weight, None, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
         else:
             y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
-        if not y.is_contiguous() or y.shape[0] * y.shape[1] > 65535:
-            return F.leaky_relu(y + c.bias.view(1, -1, 1, 1), self[1].negative_slope, inplace=True)
+        if y.dtype != torch.float32 or not y.is_contiguous() or y.shape[0] * y.shape[1] > 65535:  # (fp16: the autocast variant)
+            return F.leaky_relu(y + c.bias.to(y.dtype).view(1, -1, 1, 1), self[1].negative_slope, inplace=True)
         return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope)
 
 

@@ -52,8 +52,14 @@ def _upscale_to_multiple(images, intrinsics, m, device):
 
 
 class RobustMVD(nn.Module):
-    def __init__(self):
+    def __init__(self, half_dispnet=False):
+        """half_dispnet (an extension; the reference has no such switch; SURVEY.md 8f rank 1 names fp16 as a tuning lever
+        of the DispNet row): at inference the 2-D convolutions around the sweep — encoder, context encoder, fusion score
+        convs, cost-volume encoder, decoder — run under torch.autocast(float16) on the vendor library's fp16 kernels
+        (fp32 accumulation); the sweep (K1), the fusion arithmetic (K2) and the prediction heads' final arithmetic stay
+        fp32.  Default False = fp32 everywhere, like the reference."""
         super().__init__()
+        self.half_dispnet = bool(half_dispnet)
         self.encoder = DispnetEncoder()
         self.context_encoder = DispnetContextEncoder()
         self.corr_block = PlanesweepCorrelation()
@@ -76,6 +82,16 @@ class RobustMVD(nn.Module):
             self.corr_block.warm(sampling_type="linear_invdepth", device=dev, **self.SWEEP)
 
     def forward(self, images, poses, intrinsics, keyview_idx, **_):
+        half = self.half_dispnet and images[0].is_cuda and not torch.is_grad_enabled()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+            pred, aux = self._forward(images, poses, intrinsics, keyview_idx)
+        if half:  # the public outputs are float32 like the reference's
+            f32 = lambda v: [x.float() for x in v] if isinstance(v, list) else v.float()
+            pred = {k: f32(v) for k, v in pred.items()}
+            aux = {k: f32(v) for k, v in aux.items()}
+        return pred, aux
+
+    def _forward(self, images, poses, intrinsics, keyview_idx):
         key_pos = _key_positions(keyview_idx, images[0].shape[0])
         keyview_idx = key_pos[0] if all(k == key_pos[0] for k in key_pos) else key_pos
         image_key = select_by_index(images, keyview_idx)
@@ -102,8 +118,8 @@ class RobustMVD(nn.Module):
         all_enc_fused, enc_fused = self.fusion_enc_block(corr=fused_corr, ctx=ctx)
         dec = self.decoder(enc_fused=enc_fused, all_enc={**all_enc_key, **all_enc_fused})
 
-        pred = {"depth": 1 / (dec["invdepth"] + 1e-9),
-                "depth_uncertainty": torch.exp(dec["invdepth_log_b"]) / (dec["invdepth"] + 1e-9)}
+        inv, log_b = dec["invdepth"].float(), dec["invdepth_log_b"].float()
+        pred = {"depth": 1 / (inv + 1e-9), "depth_uncertainty": torch.exp(log_b) / (inv + 1e-9)}
         aux = dec
         aux["depth"], aux["depth_uncertainty"] = pred["depth"], pred["depth_uncertainty"]
         return pred, aux
@@ -248,7 +264,8 @@ def robust_mvd(pretrained=True, weights=None, train=False, num_gpus=1, **kwargs)
     if pretrained and weights is None:
         raise RuntimeError("robust_mvd: the pretrained weights are URL-only (robust_mvd.py:153) and there is no network; "
                            "pass weights=<path to robustmvd_600k.pt> or pretrained=False")
-    return build_model_with_cfg(model_cls=RobustMVD, weights=weights, train=train, num_gpus=num_gpus)
+    # kwargs: half_dispnet=True selects the fp16-convolution variant (extension; create_model("robust_mvd", half_dispnet=True))
+    return build_model_with_cfg(model_cls=RobustMVD, weights=weights, train=train, num_gpus=num_gpus, **kwargs)
 
 
 @register_model(trainable=False)

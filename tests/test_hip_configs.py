@@ -168,3 +168,26 @@ def test_robustmvd_forward_at_config1_vs_oracle_pipeline(dev):
     assert pred["depth"].shape == (1, H // 2, W // 2)
     np.testing.assert_allclose(aux["invdepth"], ref["invdepth"][0], atol=PATH_A_ATOL, rtol=PATH_A_ATOL)
     np.testing.assert_allclose(aux["invdepth_log_b"], ref["invdepth_log_b"][0], atol=PATH_A_ATOL, rtol=PATH_A_ATOL)
+
+
+def test_robustmvd_half_dispnet_vs_fp32(dev):
+    """half_dispnet=True (fp16 vendor convolutions under autocast, fp32 sweep / fusion / heads): an OPT-IN variant; inverse
+    depth within 2 % / 2e-2 of the fp32 model on the same weights and inputs (fp16 has 11 bits of mantissa and the
+    DispNet is ~30 layers deep).  The default stays fp32 and is what every other test checks."""
+    import robustmvd_amd as R
+    H, W, V = 448, 640, 2
+    m32 = R.RobustMVD().eval()
+    shapes = {k: tuple(v.shape) for k, v in m32.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in gc.robustmvd_weights(shapes, 5).items()}
+    m32.load_state_dict(sd)
+    m16 = R.RobustMVD(half_dispnet=True).eval()
+    m16.load_state_dict(sd)
+    m32, m16 = R.add_run_function(m32.to(dev)), R.add_run_function(m16.to(dev))
+    s = gc.synthetic_sample(9, H, W, V)
+    kw = dict(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0)
+    p32, a32 = m32.run(**kw)
+    p16, a16 = m16.run(**kw)
+    assert a16["invdepth"].dtype == np.float32 and p16["depth"].shape == p32["depth"].shape
+    np.testing.assert_allclose(a16["invdepth"], a32["invdepth"], atol=2e-2, rtol=2e-2)
+    rel = np.abs(a16["invdepth"] - a32["invdepth"]) / np.maximum(np.abs(a32["invdepth"]), 1e-3)
+    print(f"half_dispnet: median rel invdepth diff {np.median(rel):.2e}, max {rel.max():.2e}")

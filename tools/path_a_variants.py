@@ -43,3 +43,12 @@ d3 = timeit(model_cl, s_cl, "channels_last")
 print("   max rel diff vs default:", float(((d3 - ref).abs() / ref.abs().clamp_min(1e-6)).max()))
 torch.backends.cudnn.benchmark = True
 d4 = timeit(model_cl, s_cl, "channels_last + benchmark")
+torch.backends.cudnn.benchmark = False
+import robustmvd_amd as R
+mh = R.RobustMVD(half_dispnet=True).eval()
+mh.load_state_dict(BN.build_robustmvd(torch.device("cpu"))[0].state_dict()) if False else None
+mh.load_state_dict({k: v.to("cpu") for k, v in model.state_dict().items()})
+mh = mh.to(dev)
+d5 = timeit(mh, s, "half_dispnet (fp16 convs)")
+print("   max rel diff vs default:", float(((d5 - ref).abs() / ref.abs().clamp_min(1e-6)).max()),
+      " median:", float(((d5 - ref).abs() / ref.abs().clamp_min(1e-6)).median()))
