@@ -184,37 +184,55 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
             const int prev = __shfl_up(cell, 1);
             unsigned long long todo = __ballot(live && (lane == 0 || cell != prev));
             float acc = 0.f;
-            // two cells per pass: their 8 tap loads are in flight together (the loop is serial in `todo`, so one
-            // cell per pass exposed a full load latency per cell) and one 10-shuffle reduction serves both; four per
-            // pass measured no better (0.60 vs 0.58 ms: more repeated cells, a larger reduction)
-            while (todo) {  // wave-uniform
-                const int first = __builtin_ctzll(todo);
+            // two cells per step: their 8 tap loads are in flight together and one 10-shuffle reduction serves both (four per
+            // step measured no better).  The loop is serial in `todo`, so the taps of step i+1 are fetched (into a second
+            // register set) BEFORE step i is reduced: without that every step exposed a full L2 latency (round 1: 0.59 ms).
+            float ta[8][NJ], tb[8][NJ];
+            int ca0 = 0, cb0 = 0, ca1 = 0, cb1 = 0;
+            auto pick = [&](int& ca, int& cb) {  // wave-uniform
+                if (!todo) return false;
+                ca = __builtin_amdgcn_readlane(cell, __builtin_ctzll(todo));
                 todo &= todo - 1;
-                const int cu_a = __builtin_amdgcn_readlane(cell, first);
-                int cu_b = cu_a;  // odd count: the last pass does the same cell twice
+                cb = ca;  // odd count: the last step does the same cell twice
                 if (todo) {
-                    cu_b = __builtin_amdgcn_readlane(cell, __builtin_ctzll(todo));
+                    cb = __builtin_amdgcn_readlane(cell, __builtin_ctzll(todo));
                     todo &= todo - 1;
                 }
-                const float* __restrict__ spa = src + (size_t)cu_a * C;
-                const float* __restrict__ spb = src + (size_t)cu_b * C;
-                float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                return true;
+            };
+            auto issue = [&](float (&tt)[8][NJ], int ca, int cb) {
+                const float* __restrict__ spa = src + (size_t)ca * C;
+                const float* __restrict__ spb = src + (size_t)cb * C;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    d[0] = fmaf(kf[j], spa[j], d[0]);
-                    d[1] = fmaf(kf[j], spa[C + j], d[1]);
-                    d[2] = fmaf(kf[j], spa[(size_t)W2 * C + j], d[2]);
-                    d[3] = fmaf(kf[j], spa[(size_t)W2 * C + C + j], d[3]);
-                    d[4] = fmaf(kf[j], spb[j], d[4]);
-                    d[5] = fmaf(kf[j], spb[C + j], d[5]);
-                    d[6] = fmaf(kf[j], spb[(size_t)W2 * C + j], d[6]);
-                    d[7] = fmaf(kf[j], spb[(size_t)W2 * C + C + j], d[7]);
+                    tt[0][j] = spa[j]; tt[1][j] = spa[C + j];
+                    tt[2][j] = spa[(size_t)W2 * C + j]; tt[3][j] = spa[(size_t)W2 * C + C + j];
+                    tt[4][j] = spb[j]; tt[5][j] = spb[C + j];
+                    tt[6][j] = spb[(size_t)W2 * C + j]; tt[7][j] = spb[(size_t)W2 * C + C + j];
                 }
+            };
+            auto consume = [&](const float (&tt)[8][NJ], int ca, int cb) {
+                float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) d[k] = fmaf(kf[j], tt[k][j], d[k]);
                 wave_sum8(d, lane);
                 // corr = sum_taps w_tap * <f_key, f_src(tap)>, taps in grid_sample's order nw, ne, sw, se
                 const float blend_a = fmaf(d[3], t.w[3], fmaf(d[2], t.w[2], fmaf(d[1], t.w[1], d[0] * t.w[0])));
                 const float blend_b = fmaf(d[7], t.w[3], fmaf(d[6], t.w[2], fmaf(d[5], t.w[1], d[4] * t.w[0])));
-                acc = cell == cu_a ? blend_a : cell == cu_b ? blend_b : acc;
+                acc = cell == ca ? blend_a : cell == cb ? blend_b : acc;
+            };
+            bool more = pick(ca0, cb0);
+            if (more) issue(ta, ca0, cb0);
+            while (more) {  // wave-uniform
+                const bool nxt = pick(ca1, cb1);
+                if (nxt) issue(tb, ca1, cb1);
+                consume(ta, ca0, cb0);
+                if (!nxt) break;
+                more = pick(ca0, cb0);
+                if (more) issue(ta, ca0, cb0);
+                consume(tb, ca1, cb1);
             }
             if (live) {
                 res[s * SWEEP_PX + pi] = acc * inv_sqrt_c * mk;
