@@ -75,7 +75,10 @@ __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
         const bool in = e < C0_PLANE_CHUNKS && gy >= 0 && gy < h && gx >= 0 && gx < w;
         goff[k] = in ? ((gy * w + gx) * 64 + ch * 16) : -1;
-        loff[k] = e < C0_PLANE_CHUNKS ? (vox * 64 + ch * 16) : -1;
+        // the four 16-byte channel chunks of a voxel are XOR-swizzled by the voxel-pair index of its column: a fragment read
+        // (16 consecutive voxels x 4 chunks, serviced in the four 16-lane groups of ds_read_b128) then touches every bank
+        // once instead of twice (enumerated over all alignments; plain 64-B pitch: two-way conflicts everywhere)
+        loff[k] = e < C0_PLANE_CHUNKS ? (vox * 64 + ((ch ^ ((c >> 1) & 3)) * 16)) : -1;
     }
     const size_t plane_bytes = (size_t)h * w * 64;
     const char* xb = p.x + (size_t)b * D * plane_bytes;
@@ -104,8 +107,14 @@ __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
     fetch(dz0 - 1); stash(dz0 - 1);
     fetch(dz0);     stash(dz0);
     fetch(dz0 + 1);
-    // fragment address of this lane inside a slot for (row wv + kh, column group cg, kw): voxel column cg*16 + lane%16 + kw
-    const int frag0 = (wv * C0_COLS + (lane & 15)) * 64 + (lane >> 4) * 16;
+    // fragment address of this lane inside a slot for (row wv + kh, column group cg, kw): voxel column cg*16 + lane%16 + kw,
+    // chunk lane/16 at its swizzled position (cg*16 does not change the swizzle: 16/2 = 0 mod 4)
+    int fragk[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int c = (lane & 15) + kw;
+        fragk[kw] = (wv * C0_COLS + c) * 64 + (((lane >> 4) ^ ((c >> 1) & 3)) * 16);
+    }
 
     for (int d = dz0; d < dz1; ++d) {
         stash(d + 1);
@@ -114,20 +123,24 @@ __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
         f32x4 acc[4];
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) acc[cg] = f32x4{0, 0, 0, 0};
+        // 108 (tap, column group) products per plane, column group fastest (4 independent accumulators back to back).  The
+        // fragment of product i+8 is read while product i is multiplied: left to itself the compiler reads two fragments and
+        // waits for them at once, which exposes the LDS latency 54 times per plane (0.75 ms instead of 0.5).
+        const char* slots[3] = {ring + ((d + 2) % 3) * C0_PLANE_BYTES, ring + (d % 3) * C0_PLANE_BYTES,
+                                ring + ((d + 1) % 3) * C0_PLANE_BYTES};  // planes d-1, d, d+1
+        constexpr int NP = 108, DEPTH = 8;
+        f16x8 fr[DEPTH];
+        auto frag = [&](int i) {
+            const int cg = i & 3, tap = i >> 2, kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
+            return *reinterpret_cast<const f16x8*>(slots[kd] + fragk[kw] + (kh * C0_COLS + cg * 16) * 64);
+        };
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd) {
-            const char* slot = ring + ((d - 1 + kd + 3) % 3) * C0_PLANE_BYTES + frag0;
+        for (int i = 0; i < DEPTH; ++i) fr[i] = frag(i);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-                for (int cg = 0; cg < 4; ++cg) {
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const f16x8 bf = *reinterpret_cast<const f16x8*>(slot + (kh * C0_COLS + cg * 16 + kw) * 64);
-                        acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kd * 9 + kh * 3 + kw], bf, acc[cg], 0, 0, 0);
-                    }
-                }
-            }
+        for (int i = 0; i < NP; ++i) {
+            acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i >> 2], fr[i % DEPTH], acc[i & 3], 0, 0, 0);
+            if (i + DEPTH < NP) fr[i % DEPTH] = frag(i + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (row_ok) {
             float* yrow = p.y + ((((size_t)b * D + d) * h + oy) * w) * 8 + cq * 4;
