@@ -22,7 +22,7 @@ from oracle import pipeline as PL
 
 pytestmark = pytest.mark.gpu
 ATOL = RTOL = 1e-4
-PATH_A_ATOL = 2e-3  # vendor 2-D convolutions (MIOpen here, oneDNN in the oracle) differ in accumulation order
+PATH_A_ATOL = 1e-4  # Path A in inverse-depth space (vendor 2-D convolutions here, oneDNN in the oracle)
 
 CONFIGS = {1: (448, 640, 2, 128), 2: (768, 1152, 4, 256), 3: (896, 1216, 4, 256)}  # H, W, V, D  (BASELINE.json configs[i])
 

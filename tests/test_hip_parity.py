@@ -202,14 +202,14 @@ def test_robustmvd_end_to_end_golden(dev):
                   poses=[np.eye(4, dtype=np.float32), g["T0"]], keyview_idx=0)
     pred, aux = model.run(**sample)
     assert pred["depth"].shape == (1, 192, 288)
-    # 2-D convs run on MIOpen here and on oneDNN in the reference: their fp32 accumulation order differs,
-    # so the end-to-end tolerance is wider than the block tolerance (inverse-depth space)
-    np.testing.assert_allclose(aux["invdepth"], g["invdepth"], atol=2e-3, rtol=2e-3)
-    np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=2e-3, rtol=2e-3)
-    np.testing.assert_allclose(aux["invdepths_all"][0], g["invdepths_all_0"], atol=2e-3, rtol=2e-3)
-    np.testing.assert_allclose(aux["invdepths_all"][3], g["invdepths_all_3"], atol=2e-3, rtol=2e-3)
+    # Path A's final prediction in inverse-depth space at atol 1e-4.  The 2-D convolutions run on the vendor
+    # library (Winograd / implicit GEMM) here and on oneDNN in the reference; measured difference 2e-6 (tools/path_a_parity.py)
+    np.testing.assert_allclose(aux["invdepth"], g["invdepth"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(aux["invdepths_all"][0], g["invdepths_all_0"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(aux["invdepths_all"][3], g["invdepths_all_3"], atol=1e-4, rtol=1e-4)
     valid = g["invdepth"][0] > 1e-2
-    np.testing.assert_allclose(pred["depth"][0][valid], g["depth"][0][valid], rtol=5e-2)
+    np.testing.assert_allclose(pred["depth"][0][valid], g["depth"][0][valid], rtol=1e-3)
 
 
 def test_robustmvd_two_sources_golden(dev):
@@ -221,8 +221,8 @@ def test_robustmvd_two_sources_golden(dev):
     K2 = gc.synthetic_intrinsics(H2, W2)
     poses = [gc.synthetic_pose(rng), np.eye(4, dtype=np.float32), gc.synthetic_pose(rng)]
     pred, aux = model.run(images=images, intrinsics=[K2, K2, K2], poses=poses, keyview_idx=1)
-    np.testing.assert_allclose(aux["invdepth"], g["invdepth"], atol=2e-3, rtol=2e-3)
-    np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(aux["invdepth"], g["invdepth"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=1e-4, rtol=1e-4)
 
 
 def test_dispnet_conv_epilogue_is_bit_identical_to_torch(dev):

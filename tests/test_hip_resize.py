@@ -60,7 +60,7 @@ def test_robustmvd_runs_on_sample_data_layout(dev):
     assert pred["depth"].shape == (1, 384, 640)
     ref = PL.robustmvd_forward([(im / 255.0 - 0.4).astype(np.float32)[None] for im in ims], [p[None] for p in s["poses"]],
                                [(k / scale)[None] for k in intr], 0, sd)
-    np.testing.assert_allclose(aux["invdepth"], ref["invdepth"][0], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(aux["invdepth"], ref["invdepth"][0], atol=1e-4, rtol=1e-4)
 
 
 def test_mvsnet_runs_on_non_multiple_of_32(dev):
