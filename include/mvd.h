@@ -277,6 +277,11 @@ int mvd_fuse_views_backward_f32(const float* const* corr, const float* const* ma
 int mvd_resize_order1_f32(const float* src, float* dst, long long planes, int hi, int wi, int ho, int wo,
                           mvd_stream_t stream);
 
+/* Prediction head of the DispNet decoder in one pass (rmvd/models/blocks/dispnet_decoder.py:17-22,126-138; ReLUAndSigmoid,
+ * blocks/utils.py:30-41 with min -10 / max 10): x (N,2,HW) = output of a pred_k convolution;
+ * pred (N,2,HW): channel 0 = relu(x0), channel 1 = sigmoid(x1 * 0.2) * 20 - 10; ent (N,1,HW) = log(2 exp(pred1) + 1e-4) + 1. */
+int mvd_dispnet_head_f32(const float* x, float* pred, float* ent, int N, long long HW, mvd_stream_t stream);
+
 /* layout helpers used at the operator-level boundary (reference tensors are NCHW / NCDHW) */
 int mvd_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);
 int mvd_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, long long HW, mvd_stream_t stream);

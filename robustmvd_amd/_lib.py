@@ -67,6 +67,7 @@ SIGNATURES = {
                                + [ctypes.c_void_p]),
     "mvd_softmax_regress_f32": (_i, [_c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "mvd_bias_leaky_relu_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]),
+    "mvd_dispnet_head_f32": (_i, [_c_float_p, _c_float_p, _c_float_p, _i, ctypes.c_longlong, ctypes.c_void_p]),
     "mvd_arm_kernel_timing": (_i, [ctypes.c_void_p, ctypes.c_void_p]),
     "mvd_warp_variance_backward_workspace_bytes": (_sz, [_i]),
     "mvd_warp_variance_backward_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p, _c_float_p] + [_i] * 6

@@ -428,14 +428,28 @@ class DispnetDecoder(nn.Module):
         preds.setdefault("invdepths_all", []).append(mean)
         preds["invdepth_uncertainty"], preds["invdepth_log_b"], preds["invdepth"] = ent, log_b, mean
 
+    def _head(self, lvl, feat, preds):
+        """pred_k block + _record.  At inference on the GPU in fp32 the activation and the entropy are ONE engine launch
+        (ops.dispnet_head) instead of torch's ~10 elementwise kernels per head; same formulas."""
+        blk = getattr(self, f"pred_{lvl}")
+        if torch.is_grad_enabled() or not feat.is_cuda or feat.dtype != torch.float32:
+            pred = blk(feat)
+            self._record(pred, preds)
+            return pred
+        pred, ent = ops.dispnet_head(blk[0](feat))
+        mean, log_b = pred[:, 0:1], pred[:, 1:2]
+        preds.setdefault("invdepth_uncertainties_all", []).append(ent)
+        preds.setdefault("invdepth_log_bs_all", []).append(log_b)
+        preds.setdefault("invdepths_all", []).append(mean)
+        preds["invdepth_uncertainty"], preds["invdepth_log_b"], preds["invdepth"] = ent, log_b, mean
+        return pred
+
     def forward(self, enc_fused, all_enc):
         preds = {}
-        feat, pred = enc_fused, self.pred_0(enc_fused)
-        self._record(pred, preds)
+        feat, pred = enc_fused, self._head(0, enc_fused, preds)
         for lvl, skip in enumerate(self.SKIPS, start=1):
             up = getattr(self, f"deconv_{lvl}")(feat)
             pred_up = F.interpolate(pred, size=up.shape[-2:], mode="bilinear", align_corners=False).detach()
             feat = getattr(self, f"rfeat{lvl}")(torch.cat((all_enc[skip], up, pred_up), 1))
-            pred = getattr(self, f"pred_{lvl}")(feat)
-            self._record(pred, preds)
+            pred = self._head(lvl, feat, preds)
         return preds

@@ -89,9 +89,37 @@ __global__ void __launch_bounds__(256) bias_leaky_relu_kernel(float* __restrict_
         }
     }
 }
+
+// Prediction head of the DispNet decoder (rmvd/models/blocks/dispnet_decoder.py:17-22,126-138 with ReLUAndSigmoid,
+// blocks/utils.py:30-41, min = -10, max = 10): from the 2-channel output x of a pred_k convolution
+//   pred[:,0] = relu(x0)                                   inverse depth
+//   pred[:,1] = sigmoid(x1 * (4/20)) * 20 + (-10)          log b
+//   ent       = log(2 * exp(pred[:,1]) + 1e-4) + 1         entropy of the Laplace distribution
+// in one pass: torch runs this as ~10 elementwise launches per head, 6 heads per frame.
+__global__ void __launch_bounds__(256) dispnet_head_kernel(const float* __restrict__ x, float* __restrict__ pred,
+                                                           float* __restrict__ ent, long long HW) {
+    const long long n = blockIdx.y;
+    const float* __restrict__ x0 = x + n * 2 * HW;
+    float* __restrict__ p0 = pred + n * 2 * HW;
+    float* __restrict__ e0 = ent + n * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+        const float a = x0[i], bq = x0[HW + i];
+        const float sg = 1.0f / (1.0f + expf(-(bq * 0.2f)));
+        const float lb = sg * 20.0f + -10.0f;
+        p0[i] = fmaxf(a, 0.0f);
+        p0[HW + i] = lb;
+        e0[i] = logf(2.0f * expf(lb) + 1e-4f) + 1.0f;
+    }
+}
 }  // namespace mvd
 
 extern "C" {
+int mvd_dispnet_head_f32(const float* x, float* pred, float* ent, int N, long long HW, mvd_stream_t stream) {
+    MVD_REQUIRE(x && pred && ent && N > 0 && N <= 65535 && HW > 0, "dispnet_head: bad argument");
+    const unsigned gx = (unsigned)((HW + 255) / 256 > 1024 ? 1024 : (HW + 255) / 256);
+    hipLaunchKernelGGL(mvd::dispnet_head_kernel, dim3(gx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, pred, ent, HW);
+    return mvd::launch_status("dispnet_head");
+}
 int mvd_bias_leaky_relu_f32(float* x, const float* bias, int N, int C, long long HW, float slope, mvd_stream_t stream) {
     MVD_REQUIRE(x && bias && N > 0 && C > 0 && HW > 0, "bias_leaky_relu: bad argument");
     MVD_REQUIRE((long long)N * C <= 65535, "bias_leaky_relu: N*C = %lld exceeds the grid limit", (long long)N * C);

@@ -735,7 +735,10 @@ __device__ __forceinline__ void gather_blend_4planes_2sets(float4 (&s1)[4], floa
 
 // F16: features are fp16 zero-bordered channel-last maps (64 B per pixel), the volume is written as fp16 (B,D,h,w,32);
 // positions, weights, blend and variance stay fp32 (mvd_warp_variance_f16, BASELINE configs[3]).
-template <int MINW, int NSETS, bool F16 = false>
+// WP (wave-private locate): every wave locates the 128 (pixel, plane, view) combinations of ITS OWN 8 pixels (2 per lane;
+// the two half-waves take even / odd views, so the transforms come from a small LDS table instead of the scalar cache) and
+// is the only reader of those table entries: no workgroup barrier inside the march, the four waves drift apart freely.
+template <int MINW, int NSETS, bool F16 = false, bool WP = false>
 __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpParams p, int nch) {
     constexpr int DPB = 4, PPB = 32;
     constexpr unsigned PIX = F16 ? 64 : 128;  // bytes per pixel
@@ -777,6 +780,45 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
     const float xhi = (float)w, yhi = (float)h;
     const float W2f = (float)W2;
     const int v_first = __builtin_amdgcn_readfirstlane(tid >> 7);
+    // wave-private form: lane = (pixel of this wave l&7, plane (l>>3)&3, view parity l>>5)
+    float4* __restrict__ mtab = lds_raw + 2 * half_q + 256;  // [V][3] float4: the composed transforms (WP only)
+    if constexpr (WP) {
+        if (tid < V * 3) {
+            cfloat* Mg = (cfloat*)(p.M + ((size_t)(tid / 3) * p.B + b) * 12 + (tid % 3) * 4);
+            mtab[tid] = make_float4(Mg[0], Mg[1], Mg[2], Mg[3]);
+        }
+    }
+    auto locate_wp = [&](int c) {
+        float4* __restrict__ loc = lds_raw;
+        unsigned* __restrict__ offs = reinterpret_cast<unsigned*>(loc + V * (DPB * PPB));
+        // lane-derived values are recomputed from an opaque copy of the thread index (a few integer ops per chunk) instead of
+        // living in registers across the whole march: the kernel sits exactly at the 128-VGPR boundary of 4 waves per SIMD
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int wpx = (t_ >> 6) * 8 + (t_ & 7), wpi = (t_ >> 3) & 3, wvp = (t_ >> 5) & 1;
+        const float wfx = (float)min(x0 + wpx, w - 1);
+        const int d0 = c * DPB;
+        const float e0 = dvals[min(d0, D - 1)], e1 = dvals[min(d0 + 1, D - 1)], e2 = dvals[min(d0 + 2, D - 1)],
+                    e3 = dvals[min(d0 + 3, D - 1)];
+        const float depth = wpi == 0 ? e0 : wpi == 1 ? e1 : wpi == 2 ? e2 : e3;
+        for (int v = wvp; v < V; v += 2) {
+            const float4 m0 = mtab[v * 3], m1 = mtab[v * 3 + 1], m2 = mtab[v * 3 + 2];
+            const float ax = fmaf(m0.x, wfx, fmaf(m0.y, lfy, m0.z));
+            const float ay = fmaf(m1.x, wfx, fmaf(m1.y, lfy, m1.z));
+            const float az = fmaf(m2.x, wfx, fmaf(m2.y, lfy, m2.z));
+            const float X = fmaf(ax, depth, m0.w), Y = fmaf(ay, depth, m1.w), Z = fmaf(az, depth, m2.w);
+            const float rz = __builtin_amdgcn_rcpf(Z);
+            float ix = fmaf(X * rz, sx, -0.5f), iy = fmaf(Y * rz, sy, -0.5f);
+            ix = __builtin_amdgcn_fmed3f(ix, -1.0f, xhi);
+            iy = __builtin_amdgcn_fmed3f(iy, -1.0f, yhi);
+            const float xf = floorf(ix), yf = floorf(iy);
+            const float wx = ix - xf, wy = iy - yf;
+            const float ux = 1.0f - wx, uy = 1.0f - wy;
+            const int slot = (v * DPB + wpi) * PPB + wpx;
+            loc[slot] = make_float4(ux * uy, wx * uy, ux * wy, wx * wy);
+            offs[slot] = (unsigned)(int)fmaf(yf, W2f, xf) * PIX;
+        }
+    };
     auto locate = [&](int c, int buf) {
         float4* __restrict__ loc = lds_raw + buf * half_q;
         unsigned* __restrict__ offs = reinterpret_cast<unsigned*>(loc + V * (DPB * PPB));
@@ -828,11 +870,16 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
     const unsigned out_off = ((unsigned)y * (unsigned)w + (unsigned)xc) * PIX + (unsigned)q * QB;
     const size_t plane_bytes = (size_t)h * w * PIX;
 
-    locate(c_begin, 0);
+    if constexpr (WP) __syncthreads();  // transforms and key slots are staged; no further workgroup barrier
+    else locate(c_begin, 0);
     int buf = 0;
-    for (int c = c_begin; c < c_end; ++c, buf ^= 1) {
-        __syncthreads();  // table `buf` is complete; every wave is done reading table `buf ^ 1`
-        if (c + 1 < c_end) locate(c + 1, buf ^ 1);
+    for (int c = c_begin; c < c_end; ++c, buf ^= (WP ? 0 : 1)) {
+        if constexpr (WP) {
+            locate_wp(c);  // this wave's own table entries (same-wave LDS accesses execute in order)
+        } else {
+            __syncthreads();  // table `buf` is complete; every wave is done reading table `buf ^ 1`
+            if (c + 1 < c_end) locate(c + 1, buf ^ 1);
+        }
         const float4* __restrict__ loc = lds_raw + buf * half_q;
         const unsigned* __restrict__ offs = reinterpret_cast<const unsigned*>(loc + V * (DPB * PPB));
         float4 s1[DPB], s2[DPB];
@@ -916,7 +963,8 @@ static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int
         set_error("warp_variance: %lld workgroups exceed the grid limit", nblk);
         return MVD_ERR_INVALID_ARG;
     }
-    const size_t lds = 2 * (size_t)p.V * 4 * 32 * (sizeof(float4) + sizeof(unsigned)) + 256 * sizeof(float4);  // 5 KiB per view + key
+    const size_t lds = 2 * (size_t)p.V * 4 * 32 * (sizeof(float4) + sizeof(unsigned)) + 256 * sizeof(float4) +
+                       (size_t)p.V * 3 * sizeof(float4);  // 5 KiB per view + key slots + transforms
     const dim3 grid((unsigned)nblk);
     timing_begin(st);
 #define MVD_M(MW, NS) hipLaunchKernelGGL((warp_variance_march_kernel<MW, NS>), grid, dim3(256), lds, st, p, nch)
@@ -930,6 +978,7 @@ static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int
         case 43: MVD_M(4, 3); break;
         case 52: MVD_M(5, 2); break;
         case 62: MVD_M(6, 2); break;
+        case 72: hipLaunchKernelGGL((warp_variance_march_kernel<4, 2, false, true>), grid, dim3(256), lds, st, p, nch); break;  // "M7,2,n": wave-private locate
 #endif
         default: MVD_M(4, 2); break;
     }

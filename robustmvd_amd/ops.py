@@ -428,6 +428,23 @@ def resize_order1(images, ht, wd):
 
 
 @inference_only
+def dispnet_head(x):
+    """x (N,2,h,w) raw output of a pred_k convolution -> (pred (N,2,h,w) = [relu(x0), sigmoid(0.2 x1) * 20 - 10],
+    entropy (N,1,h,w) = log(2 exp(pred1) + 1e-4) + 1) in one launch (dispnet_decoder.py:17-22,126-138)."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    if x.dim() != 4 or x.shape[1] != 2:
+        raise ValueError(f"x must be (N,2,h,w), got {tuple(x.shape)}")
+    N, _, h, w = x.shape
+    pred = torch.empty_like(x)
+    ent = torch.empty((N, 1, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mvd_dispnet_head_f32(L.ptr(x), L.ptr(pred), L.ptr(ent), N, h * w, L.stream_of(x))
+    L.check(rc, "mvd_dispnet_head_f32")
+    return pred, ent
+
+
+@inference_only
 def to_channels_last_3d(x):
     """(B,C,D,h,w) -> (B,D,h,w,C) through the library's tiled transpose."""
     lib = L.load()
