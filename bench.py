@@ -277,30 +277,22 @@ def main():
         import torch.distributed as dist
         from robustmvd_amd.registry import add_batch_dim
         from robustmvd_amd.sharding import timed_region
+        import robustmvd_amd as R
         host = []
         for f in my_frames:
             smp = gc.synthetic_sample(f, H, W, V)
             im, key, po, intr, dr = add_batch_dim(smp["images"], smp["keyview_idx"], smp["poses"], smp["intrinsics"],
                                                   (np.float32(0.5), np.float32(10.0)))
-            host.append(([torch.from_numpy(np.ascontiguousarray(x)).pin_memory() for x in im], key, po, intr, dr))
-        copy_stream = torch.cuda.Stream(dev)
-
-        def stage(i):
-            im, key, po, intr, dr = host[i % len(host)]
-            with torch.cuda.stream(copy_stream):
-                d_im = [x.to(dev, non_blocking=True) for x in im]
-                ev = torch.cuda.Event()
-                ev.record(copy_stream)
-            return d_im, key, po, intr, dr, ev
+            host.append((R.PinnedUploader.pin(im), key, po, intr, dr))
+        up = R.PinnedUploader(dev)
 
         def run_h2d(n):
-            nxt = stage(0)
+            nxt = up.stage(host[0][0])
             with torch.no_grad():
                 for i in range(n):
-                    d_im, key, po, intr, dr, ev = nxt
-                    nxt = stage(i + 1)  # next frame's upload runs under this frame's forward
-                    torch.cuda.current_stream(dev).wait_event(ev)
-                    model(**model.input_adapter(images=d_im, keyview_idx=key, poses=po, intrinsics=intr, depth_range=dr))
+                    _, key, po, intr, dr = host[i % len(host)]
+                    cur, nxt = nxt, up.stage(host[(i + 1) % len(host)][0])  # next frame's upload runs under this forward
+                    model(**model.input_adapter(images=cur.wait(), keyview_idx=key, poses=po, intrinsics=intr, depth_range=dr))
 
         run_h2d(args.warmup + 2)
         torch.cuda.synchronize(dev)

@@ -13,5 +13,5 @@ from . import models  # noqa: F401  (registers robust_mvd, robust_mvd_5M, mvsnet
 from .blocks import (PlanesweepCorrelation, LearnedFusion, CostRegNet, homo_warp, depth_regression,  # noqa: F401
                      compute_sampling_invdepths)
 from .models import RobustMVD, MVSNet  # noqa: F401
-from .serving import FramePipeline  # noqa: F401
+from .serving import FramePipeline, PinnedUploader  # noqa: F401
 from .sweep_modes import cvp_proj_cost, vis_cost_volumes, sweep_reduce  # noqa: F401

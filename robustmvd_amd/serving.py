@@ -64,3 +64,52 @@ class FramePipeline:
     def drain(self):
         for s in self.streams:
             s.synchronize()
+
+
+class PinnedUploader:
+    """Host-to-device staging of raw input images for the model adapters ("pinned-memory H2D
+    overlap"): the frame's images are copied into page-locked host buffers once (or handed over already pinned) and
+    uploaded on a dedicated copy stream, so the transfer of frame i+1 runs under the forward of frame i.
+
+        up = PinnedUploader(device)
+        nxt = up.stage(images_0)                      # list of numpy arrays / CPU tensors, any dtype
+        for i in range(n):
+            cur, nxt = nxt, up.stage(images[i + 1])   # next frame's H2D is in flight
+            dev_images = cur.wait()                   # the compute stream waits for the copy (no host sync)
+            sample = model.input_adapter(images=dev_images, ...)
+    """
+
+    class _Staged:
+        def __init__(self, tensors, event, device):
+            self._tensors, self._event, self._device = tensors, event, device
+
+        def wait(self):
+            torch.cuda.current_stream(self._device).wait_event(self._event)
+            return self._tensors
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("PinnedUploader needs a ROCm device")
+        self.stream = torch.cuda.Stream(self.device)
+
+    @staticmethod
+    def pin(images):
+        """numpy arrays / CPU tensors -> page-locked CPU tensors (reusable across frames of the same shape)."""
+        out = []
+        for im in images:
+            t = im if isinstance(im, torch.Tensor) else torch.from_numpy(im)
+            out.append(t if t.is_pinned() else t.contiguous().pin_memory())
+        return out
+
+    def stage(self, images):
+        pinned = self.pin(images)
+        with torch.cuda.stream(self.stream):
+            dev = [t.to(self.device, non_blocking=True) for t in pinned]
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        for t in dev:  # the tensors are consumed on another stream: keep the allocator from recycling them early
+            t.record_stream(torch.cuda.current_stream(self.device))
+        staged = self._Staged(dev, ev, self.device)
+        staged._pinned = pinned  # keep the host buffers alive until the copy has been consumed
+        return staged
