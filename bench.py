@@ -266,7 +266,11 @@ def main():
                             "ms_per_step": dtp / args.steps * 1e3,
                             "note": "same workload and step count, two HIP streams per process; not the headline value"}
 
-    if os.environ.get("MVD_BENCH_PIPELINED", "1") == "1":
+    # Multi-rank runs (the driver's scaling curve) measure the headline only: every extra block below contains barriers, so
+    # a failure on ONE rank would hang the others and lose the whole line.  MVD_BENCH_EXTRAS=1 forces them on; h2d_inclusive
+    # (the block SURVEY.md 8(e) cares about for scaling) stays on for every world size.
+    extras = world == 1 or os.environ.get("MVD_BENCH_EXTRAS", "0") == "1"
+    if extras and os.environ.get("MVD_BENCH_PIPELINED", "1") == "1":
         guarded("pipelined", pipelined_block)
 
     def h2d_inclusive_block():
@@ -352,7 +356,7 @@ def main():
         torch.cuda.empty_cache()
 
 
-    if not args.no_path_a and args.config in (1, 2, 3):
+    if extras and not args.no_path_a and args.config in (1, 2, 3):
         guarded("path_a", path_a_block)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
