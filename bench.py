@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, help="index into BASELINE.json configs (default 2 = headline)")
     ap.add_argument("--fp32", action="store_true", help="run configs[3] on the fp32 path instead of its named fp16-feature variant")
+    ap.add_argument("--include-h2d", action="store_true",
+                    help="multi-rank runs: also time the h2d_inclusive block (pinned host images -> copy stream -> input_adapter -> forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-path-a", action="store_true")
     args = ap.parse_args()
@@ -267,8 +269,8 @@ def main():
                             "note": "same workload and step count, two HIP streams per process; not the headline value"}
 
     # Multi-rank runs (the driver's scaling curve) measure the headline only: every extra block below contains barriers, so
-    # a failure on ONE rank would hang the others and lose the whole line.  MVD_BENCH_EXTRAS=1 forces them on; h2d_inclusive
-    # (the block SURVEY.md 8(e) cares about for scaling) stays on for every world size.
+    # a failure on ONE rank would hang the others and lose the whole line.  MVD_BENCH_EXTRAS=1 forces all of them on;
+    # --include-h2d adds just the h2d_inclusive block (what SURVEY.md 8(e) expects to limit 1 -> 8 GPU scaling).
     extras = world == 1 or os.environ.get("MVD_BENCH_EXTRAS", "0") == "1"
     if extras and os.environ.get("MVD_BENCH_PIPELINED", "1") == "1":
         guarded("pipelined", pipelined_block)
@@ -308,7 +310,7 @@ def main():
                                 "note": "raw images in pinned host memory -> copy stream (overlapped with the previous "
                                         "frame) -> input_adapter on the device -> forward; not the headline value"}
 
-    if os.environ.get("MVD_BENCH_H2D", "1") == "1":
+    if (extras or args.include_h2d) and os.environ.get("MVD_BENCH_H2D", "1") == "1":
         guarded("h2d_inclusive", h2d_inclusive_block)
     del samples
     torch.cuda.empty_cache()
