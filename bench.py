@@ -46,9 +46,9 @@ SETTLE_FORWARDS = int(os.environ.get("MVD_BENCH_SETTLE", "12"))
 HALF_FEATURES = {3}
 
 
-def build_mvsnet(D, dev, seed=0, half_features=False):
+def build_mvsnet(D, dev, seed=0, half_features=False, conv0_split=False):
     import robustmvd_amd as R
-    model = R.MVSNet(num_sampling_steps=D, half_features=half_features).eval()
+    model = R.MVSNet(num_sampling_steps=D, half_features=half_features, conv0_split=conv0_split).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = gc.fill_state_dict(shapes, seed)
     full = model.state_dict()
@@ -312,6 +312,25 @@ def main():
 
     if (extras or args.include_h2d) and os.environ.get("MVD_BENCH_H2D", "1") == "1":
         guarded("h2d_inclusive", h2d_inclusive_block)
+
+    def split_block():
+        """Extra, OPT-IN, not the headline: the same forward with the regulariser's first layer in split-operand form
+        (MVSNet(conv0_split=True): every fp32 operand of conv0 as two fp16 terms on fp16 MFMA, fp32 accumulation, dropped
+        term 2^-22 relative).  The headline keeps conv0 on the fp32 matrix instruction."""
+        ms, _ = build_mvsnet(D, dev, half_features=half, conv0_split=True)
+        with torch.no_grad():
+            d0 = model(**samples[0])[0]["depth"]
+            d1 = ms(**samples[0])[0]["depth"]
+        rel = float(((d1 - d0).abs() / d0.abs()).max())
+        dts = timed_loop(ms, samples, args.steps, args.warmup, world, dev, None, cdev)
+        out["conv0_split_operands"] = {"value": world * args.steps / dts, "unit": "depth-maps/sec", "ms_per_step": dts / args.steps * 1e3,
+                                       "max_rel_depth_diff_vs_headline_model": rel,
+                                       "note": "opt-in MVSNet(conv0_split=True): conv0 operands split into 2 fp16 terms each, fp16 MFMA, "
+                                               "fp32 accumulate; not the headline value"}
+        del ms
+
+    if extras and not half:
+        guarded("conv0_split_operands", split_block)
     del samples
     torch.cuda.empty_cache()
 

@@ -182,6 +182,15 @@ int mvd_pack_conv3d_weights_f16(const float* w, int Cin, int Cout, void* packed,
 int mvd_conv3d_bn_relu_f16in(const void* x, const void* packed_w, const float* scale, const float* shift, float* y, int B,
                              int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
 
+/* K4 first layer, OPT-IN split-operand form (the default conv0 is mvd_conv3d_bn_relu_f32 on fp32 MFMA): fp32 input and
+ * fp32 weights, each split exactly into two fp16 terms (a = a_hi + 2^-11 a_lo), products a_hi w_hi + 2^-11 (a_hi w_lo +
+ * a_lo w_hi) on v_mfma_f32_16x16x32_f16 with fp32 accumulation; the dropped term is 2^-22 a_lo w_lo, i.e. relative error per
+ * product <= ~3 * 2^-22 against fp32's own 2^-24.  x (B,D,h,w,32) fp32 -> y (B,D,h,w,8) fp32; only Cin = 32, Cout = 8. */
+size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout);
+int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream);
+int mvd_conv3d_bn_relu_f32_split(const float* x, const void* packed_w, const float* scale, const float* shift, float* y, int B,
+                                 int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
+
 /* K6 — one layer of MVSNet's FeatureNet (rmvd/models/blocks/mvsnet_components.py:44-66; ConvBnReLU :8-22) as an
  * implicit GEMM on the fp32 matrix cores: Conv2d k x k with padding k/2 (k = 3 stride 1, or k = 5 stride 2), then a
  * per-channel affine (eval-mode BatchNorm2d folded to scale/shift; scale = 1, shift = bias for the final `feature`

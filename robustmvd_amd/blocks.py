@@ -239,8 +239,12 @@ class CostRegNet(nn.Module):
               ("conv5", 32, 64, 2), ("conv6", 64, 64, 1)]
     UPS = [("conv7", 64, 32), ("conv9", 32, 16), ("conv11", 16, 8)]
 
-    def __init__(self):
+    def __init__(self, conv0_split=False):
+        """conv0_split (an extension, default off): the first layer's fp32 operands are split into two fp16 terms each and
+        multiplied on fp16 MFMA with fp32 accumulation (ops.conv3d_bn_relu_split: relative error per product ~3 * 2^-22
+        against fp32's 2^-24) instead of running on the fp32 matrix instruction."""
         super().__init__()
+        self.conv0_split = bool(conv0_split)
         for name, cin, cout, stride in self.LAYERS:
             setattr(self, name, ConvBnReLU3D(cin, cout, stride=stride))
         for name, cin, cout in self.UPS:
@@ -270,6 +274,8 @@ class CostRegNet(nn.Module):
         pk["prob"] = (w, 8, 1, torch.ones(1, device=w.device), self.prob.bias.detach().contiguous(), L.CONV3D_STRIDE1)
         # fp16-feature variant (BASELINE configs[3]): conv0's weights rounded to fp16 in fp16-MFMA fragment order
         pk["conv0_f16"] = ops.pack_conv3d_weights_f16(self.conv0.conv.weight.detach())
+        if self.conv0_split:
+            pk["conv0_split"] = ops.pack_conv3d_weights_split(self.conv0.conv.weight.detach())
         self._packed, self._packed_key = pk, key
         return pk
 
@@ -288,6 +294,9 @@ class CostRegNet(nn.Module):
         if x.dtype == torch.float16:  # the fp16 volume of ops.warp_variance_f16: first layer on fp16 MFMA, fp32 out
             _, _, _, scale0, shift0, _ = pk["conv0"]
             conv0 = ops.conv3d_bn_relu_f16in(x, pk["conv0_f16"], scale0, shift0, relu=True)
+        elif self.conv0_split:
+            _, _, _, scale0, shift0, _ = pk["conv0"]
+            conv0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True)
         else:
             conv0 = layer("conv0", x)
         conv2 = layer("conv2", layer("conv1", conv0))

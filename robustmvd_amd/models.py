@@ -146,7 +146,7 @@ class RobustMVD(nn.Module):
 
 
 class MVSNet(nn.Module):
-    def __init__(self, sample_in_inv_depth_space=False, num_sampling_steps=192, half_features=False):
+    def __init__(self, sample_in_inv_depth_space=False, num_sampling_steps=192, half_features=False, conv0_split=False):
         """half_features (an extension; the reference has no such switch): BASELINE.json configs[3] — the feature maps
         are rounded to fp16 before the sweep, the variance volume is stored fp16 and the regulariser's first layer runs
         on fp16 MFMA with fp32 accumulation; everything else (positions, blend, variance, layers 2..11, soft argmin)
@@ -157,7 +157,7 @@ class MVSNet(nn.Module):
             raise NotImplementedError("sample_in_inv_depth_space=True is a dead branch in the reference "
                                       "(tensor[::-1] raises, mvsnet.py:50,56-63)")
         self.feature = FeatureNet()
-        self.cost_regularization = CostRegNet()
+        self.cost_regularization = CostRegNet(conv0_split=conv0_split)  # opt-in split-operand first layer, see CostRegNet
         self.num_sampling_steps = num_sampling_steps
         self.sample_in_inv_depth_space = False
         self._intrinsics_scale_host = torch.tensor([[0.25] * 3, [0.25] * 3, [1.0] * 3])  # feature maps are 1/4 resolution

@@ -318,6 +318,40 @@ def conv3d_bn_relu_f16in(x, packed, scale, shift, relu=True):
 
 
 @inference_only
+def pack_conv3d_weights_split(weight):
+    """weight: Conv3d (8,32,3,3,3) fp32 -> [w_hi | w_lo] fp16 fragments for conv3d_bn_relu_split."""
+    lib = L.load()
+    wt = L.as_f32(weight, "weight")
+    if tuple(wt.shape) != (8, 32, 3, 3, 3):
+        raise ValueError(f"conv3d split: only the 32 -> 8 first layer is built, got weight {tuple(wt.shape)}")
+    packed = torch.empty(lib.mvd_conv3d_split_packed_weight_bytes(32, 8), dtype=torch.uint8, device=wt.device)
+    with torch.cuda.device(wt.device):
+        rc = lib.mvd_pack_conv3d_weights_split(L.ptr(wt), 32, 8, L.ptr(packed), L.stream_of(wt))
+    L.check(rc, "mvd_pack_conv3d_weights_split")
+    return packed
+
+
+@inference_only
+def conv3d_bn_relu_split(x, packed, scale, shift, relu=True):
+    """K4 first layer, opt-in split-operand form: x (B,D,h,w,32) fp32 -> (B,D,h,w,8) fp32 on fp16 MFMA with two-term
+    operand splitting (relative error per product ~3 * 2^-22; mvd_conv3d_bn_relu_f32_split)."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    if x.dim() != 5 or x.shape[-1] != 32:
+        raise ValueError(f"x must be (B,D,h,w,32) channel-last, got {tuple(x.shape)}")
+    B, D, h, w, _ = x.shape
+    dev = x.device
+    scale = L.as_f32(scale, "scale", (8,), dev)
+    shift = L.as_f32(shift, "shift", (8,), dev)
+    y = torch.empty((B, D, h, w, 8), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_conv3d_bn_relu_f32_split(L.ptr(x), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), B, D, h, w, 32, 8,
+                                              int(bool(relu)), L.stream_of(x))
+    L.check(rc, "mvd_conv3d_bn_relu_f32_split")
+    return y
+
+
+@inference_only
 def pack_conv2d_weights(weight):
     """weight: Conv2d (Cout,Cin,k,k), k in (3, 5) -> (packed, Cin, Cout, k)."""
     lib = L.load()

@@ -114,3 +114,47 @@ def test_mvsnet_half_features_at_config3_vs_fp32_oracle(dev):
     assert pred["depth"].shape == (1, 224, 304)
     rel = np.abs(pred["depth"] - ref["depth"][0]) / ref["depth"][0]
     print(f"configs[3] half_features: max rel depth error {rel.max():.2e}, median {np.median(rel):.2e}")
+
+
+@pytest.mark.parametrize("D,h,w", [(5, 7, 50), (9, 12, 130), (33, 6, 64), (4, 17, 16)])
+def test_conv0_split_operands_vs_fp32_kernel_and_oracle(D, h, w, dev):
+    """OPT-IN split-operand conv0 (two fp16 terms per fp32 operand, fp16 MFMA, fp32 accumulate) against the default
+    fp32-MFMA kernel on the same fp32 data: fp32-grade agreement (the dropped a_lo*w_lo term is 2^-22 relative), and against
+    the C oracle at the block tolerance."""
+    from robustmvd_amd import ops, _lib as L
+    rng = np.random.default_rng(D * 7 + w)
+    x = (rng.standard_normal((32, D, h, w)) * rng.choice([1e-3, 1.0, 30.0], size=(32, 1, 1, 1))).astype(np.float32)
+    wt = (rng.standard_normal((8, 32, 3, 3, 3)) * np.sqrt(2 / (32 * 27))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 8).astype(np.float32)
+    shift = (rng.standard_normal(8) * 0.1).astype(np.float32)
+    xt = T(x, dev).permute(1, 2, 3, 0).contiguous()[None]
+    got = ops.conv3d_bn_relu_split(xt, ops.pack_conv3d_weights_split(T(wt, dev)), T(scale, dev), T(shift, dev))
+    w32, _, _ = ops.pack_conv3d_weights(T(wt, dev), L.CONV3D_STRIDE1)
+    base = ops.conv3d_bn_relu(xt, w32, 32, 8, T(scale, dev), T(shift, dev), L.CONV3D_STRIDE1, relu=True)
+    ref = CO.conv3d(x, wt, scale, shift, stride=1, relu=True)
+    g, b_ = got[0].permute(3, 0, 1, 2).cpu().numpy(), base[0].permute(3, 0, 1, 2).cpu().numpy()
+    mag = np.abs(ref).max()
+    assert np.abs(g - b_).max() <= 4e-6 * mag, np.abs(g - b_).max() / mag      # fp32-grade: both are ~1e-6 from the exact sum
+    assert np.abs(g.astype(np.float64) - ref).max() <= 2.0 * max(np.abs(b_.astype(np.float64) - ref).max(), 1e-6 * mag)
+    np.testing.assert_allclose(g, ref, atol=1e-4 * max(mag, 1.0), rtol=1e-4)
+
+
+def test_mvsnet_conv0_split_matches_default_model(dev):
+    """MVSNet(conv0_split=True) against the default fp32 model on the same weights and inputs: regressed depth within 1e-5."""
+    import robustmvd_amd as R
+    H, W, V, D = 128, 192, 2, 32
+    m0 = R.MVSNet(num_sampling_steps=D).eval()
+    shapes = {k: tuple(v.shape) for k, v in m0.state_dict().items()}
+    sd = gc.fill_state_dict(shapes, 8)
+    full = m0.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    m0.load_state_dict(full)
+    m1 = R.MVSNet(num_sampling_steps=D, conv0_split=True).eval()
+    m1.load_state_dict(full)
+    m0, m1 = R.add_run_function(m0.to(dev)), R.add_run_function(m1.to(dev))
+    s = gc.synthetic_sample(4, H, W, V)
+    kw = dict(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0, depth_range=(np.float32(0.5), np.float32(10.0)))
+    p0, _ = m0.run(**kw)
+    p1, _ = m1.run(**kw)
+    np.testing.assert_allclose(p1["depth"], p0["depth"], rtol=1e-5)
