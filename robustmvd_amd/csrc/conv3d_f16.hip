@@ -42,7 +42,7 @@ struct Conv0Params {
     const float* shift;   // (8)
     float* y;             // (B, D, h, w, 8) fp32
     int B, D, h, w, relu;
-    int tiles_x, tiles_y, dgroups, td;
+    int tiles_x, tiles_y, dgroups, td, tiles_per_xcd;
 };
 
 __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
@@ -51,11 +51,16 @@ __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
     const int D = p.D, h = p.h, w = p.w;
 
     // block -> (batch, depth group, tile); tiles fastest so that neighbouring tiles (shared halo rows) run together
-    int j = blockIdx.x;
-    const int tx = j % p.tiles_x; j /= p.tiles_x;
-    const int ty = j % p.tiles_y; j /= p.tiles_y;
+    // XCD-aware decode (blocks b and b + 8 share an XCD and its L2): each XCD owns a contiguous run of (row-major) tiles, so
+    // the halo rows and columns that neighbouring tiles share are re-read from ONE L2 instead of from HBM by eight
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int t_in = j % p.tiles_per_xcd; j /= p.tiles_per_xcd;
     const int dg = j % p.dgroups;
     const int b = j / p.dgroups;
+    const int tile = xcd * p.tiles_per_xcd + t_in;
+    if (tile >= p.tiles_x * p.tiles_y) return;  // block-uniform
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int x0 = tx * C0_TW, y0 = ty * C0_TH;
     const int dz0 = dg * p.td, dz1 = min(dz0 + p.td, D);
 
@@ -185,12 +190,13 @@ int mvd_conv3d_bn_relu_f16in(const void* x, const void* packed_w, const float* s
     p.tiles_x = (w + mvd::C0_TW - 1) / mvd::C0_TW;
     p.tiles_y = (h + mvd::C0_TH - 1) / mvd::C0_TH;
     // planes per workgroup: long marches amortise the two-plane ring fill, but the grid must still fill 256 CUs x 2
-    const long long tiles = (long long)p.tiles_x * p.tiles_y * B;
+    const long long tiles = (long long)p.tiles_x * p.tiles_y;
+    p.tiles_per_xcd = (int)((tiles + 7) / 8);
     int td = 32;
-    while (td > 8 && tiles * ((D + td - 1) / td) < 2048) td /= 2;
+    while (td > 8 && tiles * B * ((D + td - 1) / td) < 2048) td /= 2;
     p.td = td;
     p.dgroups = (D + td - 1) / td;
-    const long long nblk = tiles * p.dgroups;
+    const long long nblk = 8LL * p.tiles_per_xcd * p.dgroups * B;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv3d_f16in: %lld workgroups exceed the grid limit", nblk);
     const size_t lds = 3 * (size_t)mvd::C0_PLANE_BYTES;
     (void)hipFuncSetAttribute((const void*)mvd::conv0_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

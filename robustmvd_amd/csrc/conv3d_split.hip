@@ -49,7 +49,7 @@ struct SplitParams {
     const float* shift;
     float* y;             // (B, D, h, w, 8) fp32
     int B, D, h, w, relu;
-    int tiles_x, tiles_y, dgroups, td;
+    int tiles_x, tiles_y, dgroups, td, tiles_per_xcd;
 };
 
 __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
@@ -62,11 +62,16 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int D = p.D, h = p.h, w = p.w;
 
-    int j = blockIdx.x;
-    const int tx = j % p.tiles_x; j /= p.tiles_x;
-    const int ty = j % p.tiles_y; j /= p.tiles_y;
+    // XCD-aware decode (blocks b and b + 8 share an XCD and its L2): each XCD owns a contiguous run of (row-major) tiles, so
+    // the halo rows and columns that neighbouring tiles share are re-read from ONE L2 instead of from HBM by eight
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int t_in = j % p.tiles_per_xcd; j /= p.tiles_per_xcd;
     const int dg = j % p.dgroups;
     const int b = j / p.dgroups;
+    const int tile = xcd * p.tiles_per_xcd + t_in;
+    if (tile >= p.tiles_x * p.tiles_y) return;  // block-uniform
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int x0 = tx * S_TW, y0 = ty * S_TH;
     const int dz0 = dg * p.td, dz1 = min(dz0 + p.td, D);
 
@@ -214,12 +219,13 @@ int mvd_conv3d_bn_relu_f32_split(const float* x, const void* packed_w, const flo
     p.B = B; p.D = D; p.h = h; p.w = w; p.relu = relu;
     p.tiles_x = (w + mvd::S_TW - 1) / mvd::S_TW;
     p.tiles_y = (h + mvd::S_TH - 1) / mvd::S_TH;
-    const long long tiles = (long long)p.tiles_x * p.tiles_y * B;
+    const long long tiles = (long long)p.tiles_x * p.tiles_y;
+    p.tiles_per_xcd = (int)((tiles + 7) / 8);
     int td = 32;
-    while (td > 8 && tiles * ((D + td - 1) / td) < 2048) td /= 2;
+    while (td > 8 && tiles * B * ((D + td - 1) / td) < 2048) td /= 2;
     p.td = td;
     p.dgroups = (D + td - 1) / td;
-    const long long nblk = tiles * p.dgroups;
+    const long long nblk = 8LL * p.tiles_per_xcd * p.dgroups * B;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv3d_split: %lld workgroups exceed the grid limit", nblk);
     const size_t lds = 3 * (size_t)mvd::S_PLANE_BYTES;
     (void)hipFuncSetAttribute((const void*)mvd::conv0_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
