@@ -12,8 +12,8 @@
 // useful), a second with A = a_lo yields a_lo w_hi (half useful).  2 MFMAs of 16 cycles per (tap, 16 voxels) replace 8
 // fp32 MFMAs of 32 cycles: the layer turns from matrix-bound into an LDS / memory pass.
 //
-// Workgroup (4 waves) = 4 x 32 tile marching through TD planes with a 3-plane LDS ring; the fp32 volume is converted to the
-// two fp16 terms while it is staged (global -> registers -> LDS), all 27 weight fragments stay in registers.
+// Workgroup (4 waves) = 4 x 32 tile marching through TD + 2 input planes (see the kernel); the fp32 volume is converted to
+// the two fp16 terms while it is staged (global -> registers -> LDS), all 27 weight fragments stay in registers.
 #include "mvd_common.h"
 
 namespace mvd {
@@ -57,8 +57,15 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// Plane-stationary march.  One input plane z is staged per step and every activation fragment read from LDS is used for all
+// the outputs it feeds in d and y: the three output planes z-1, z, z+1 (taps kd = 2, 1, 0) and the wave's two output rows
+// (taps kh = rr - row).  24 fragment reads feed the 108 MFMAs of a step (4.5 per read); with one read per MFMA (the first
+// version, profiles/r02_conv0_split_pmc.txt) the four SIMDs of a CU asked the LDS for 32 clocks of ds_read_b128 per 16
+// clocks of MFMA and the kernel sat on the LDS port at 35 % matrix utilisation.  Three output planes of accumulators are in
+// flight per wave (48 VGPRs); the LDS holds two plane slots (the one being read, the one being written).
+// wave wv: columns 16 (wv & 1) .. +15, output rows 2 (wv >> 1), +1 of the 4 x 32 tile.
 __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
-    extern __shared__ __attribute__((aligned(16))) char ring[];  // 3 planes x (hi part | lo part)
+    extern __shared__ __attribute__((aligned(16))) char ring[];  // 2 planes x (hi part | lo part)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int D = p.D, h = p.h, w = p.w;
 
@@ -79,8 +86,13 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 #pragma unroll
     for (int t = 0; t < 27; ++t) wf[t] = *reinterpret_cast<const h16x8*>(p.wpk + ((size_t)t * 64 + lane) * 16);
 
-    // staging map: item e = tid + 256 k -> (row, col, 8-channel chunk)
-    int goff[S_NLOAD], loff[S_NLOAD];
+    // staging map: item e = tid + 256 k -> (row, col, 8-channel chunk).  Everything below is branch-free: a voxel outside the
+    // plane (or a plane outside the volume) is an out-of-range buffer offset (reads 0), the 208 idle items of the last round
+    // write to a dump row behind the two slots.  With branches the compiler cannot count what is outstanding and falls back to
+    // vmcnt(0), which also waits for the stores.
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned gob[S_NLOAD];
+    int loff[S_NLOAD];
 #pragma unroll
     for (int k = 0; k < S_NLOAD; ++k) {
         const int e = tid + 256 * k;
@@ -88,29 +100,28 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
         const int r = vox / S_COLS, c = vox - r * S_COLS;
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
         const bool in = e < S_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        goff[k] = in ? ((gy * w + gx) * 32 + ch * 8) : -1;                                   // floats inside a plane
+        gob[k] = in ? (unsigned)(((gy * w + gx) * 32 + ch * 8) * 4) : OOB;                  // bytes inside a plane
         loff[k] = e < S_ITEMS ? (vox * 64 + ((ch ^ ((c >> 1) & 3)) * 16)) : -1;             // swizzled as in conv0_f16
     }
     const size_t plane_f = (size_t)h * w * 32;
     const float* xb = p.x + (size_t)b * D * plane_f;
-    float4 pre[S_NLOAD][2];
+    su32x4 pre[S_NLOAD][2];
     auto fetch = [&](int d) {
-        const bool din = d >= 0 && d < D;  // block-uniform
+        const bool din = d >= 0 && d < D && d <= dz1;  // block-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xb + (din ? (size_t)d * plane_f : 0)), 0, din ? (int)(plane_f * 4) : 0, 0x00020000);
 #pragma unroll
         for (int k = 0; k < S_NLOAD; ++k) {
-            pre[k][0] = pre[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (din && goff[k] >= 0) {
-                const float4* src = reinterpret_cast<const float4*>(xb + (size_t)d * plane_f + goff[k]);
-                pre[k][0] = src[0];
-                pre[k][1] = src[1];
-            }
+            pre[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, gob[k], 0, 0);
+            pre[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, gob[k] + 16u, 0, 0);
         }
     };
-    auto stash = [&](int d) {  // split into the two fp16 terms on the way into the ring
-        char* slot = ring + ((d + 3) % 3) * S_PLANE_BYTES;
+    char* const dump = ring + 2 * S_PLANE_BYTES + tid * 16;
+    auto stash = [&](int d) {  // split into the two fp16 terms on the way into the LDS
+        char* slot = ring + (d & 1) * S_PLANE_BYTES;
 #pragma unroll
         for (int k = 0; k < S_NLOAD; ++k) {
-            const float4 a = pre[k][0], c = pre[k][1];
+            const sf32x4 a = __builtin_bit_cast(sf32x4, pre[k][0]), c = __builtin_bit_cast(sf32x4, pre[k][1]);
             const _Float16 h0 = (_Float16)a.x, h1 = (_Float16)a.y, h2 = (_Float16)a.z, h3 = (_Float16)a.w;
             const _Float16 h4 = (_Float16)c.x, h5 = (_Float16)c.y, h6 = (_Float16)c.z, h7 = (_Float16)c.w;
             const su32x4 hv = {pack_h2(h0, h1), pack_h2(h2, h3), pack_h2(h4, h5), pack_h2(h6, h7)};
@@ -118,80 +129,110 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
                                pack_h2((_Float16)((a.z - (float)h2) * 2048.0f), (_Float16)((a.w - (float)h3) * 2048.0f)),
                                pack_h2((_Float16)((c.x - (float)h4) * 2048.0f), (_Float16)((c.y - (float)h5) * 2048.0f)),
                                pack_h2((_Float16)((c.z - (float)h6) * 2048.0f), (_Float16)((c.w - (float)h7) * 2048.0f))};
-            if (loff[k] >= 0) {
-                *reinterpret_cast<su32x4*>(slot + loff[k]) = hv;
-                *reinterpret_cast<su32x4*>(slot + S_HALF_BYTES + loff[k]) = lv;
-            }
+            char* dst = loff[k] >= 0 ? slot + loff[k] : dump;
+            *reinterpret_cast<su32x4*>(dst) = hv;
+            *reinterpret_cast<su32x4*>(loff[k] >= 0 ? dst + S_HALF_BYTES : dst) = lv;
         }
     };
 
     // epilogue constants of the lanes that end up with a result: column (cout) l%16 < 8
     const int col = lane & 15;
-    const float esc = p.scale[col & 7], esh = p.shift[col & 7];
-    const int oy = y0 + wv;
+    float esc_ = p.scale[col & 7], esh_ = p.shift[col & 7];
+    const int xh = wv & 1, rp = wv >> 1;
 
-    fetch(dz0 - 1); stash(dz0 - 1);
-    fetch(dz0);     stash(dz0);
-    fetch(dz0 + 1);
     int fragk[3];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int c = (lane & 15) + kw;
-        fragk[kw] = (wv * S_COLS + c) * 64 + (((lane >> 4) ^ ((c >> 1) & 3)) * 16);
+        const int c = 16 * xh + (lane & 15) + kw;
+        fragk[kw] = (2 * rp * S_COLS + c) * 64 + (((lane >> 4) ^ ((c >> 1) & 3)) * 16);
     }
 
-    for (int d = dz0; d < dz1; ++d) {
-        stash(d + 1);
-        __syncthreads();
-        fetch(d + 2);
-        sf32x4 acc1[2], acc2[2];  // a_hi x [w_hi | w_lo],  a_lo x [w_hi | (w_lo: unused)]
+    // acc[plane slot][row][term]: slot 0 = output plane z-1 (finishes this step), 1 = plane z, 2 = plane z+1 (starts);
+    // fin = the plane that finished in the previous step, stored after this step's barrier
+    sf32x4 acc[3][2][2], fin[2][2];
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) { acc1[cg] = sf32x4{0, 0, 0, 0}; acc2[cg] = sf32x4{0, 0, 0, 0}; }
-        const char* slots[3] = {ring + ((d + 2) % 3) * S_PLANE_BYTES, ring + (d % 3) * S_PLANE_BYTES,
-                                ring + ((d + 1) % 3) * S_PLANE_BYTES};
-        // product i = (tap, column group, term): 27 x 2 x 2 = 108 per plane, fragment reads pipelined 8 deep by hand
-        constexpr int NP = 108, DEPTH = 8;
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { acc[s][r][0] = sf32x4{0, 0, 0, 0}; acc[s][r][1] = sf32x4{0, 0, 0, 0}; }
+
+    // lane l holds voxels 4*(l/16) .. +3 of column l%16: columns 0..7 = hi*hi for cout c, columns 8..15 = hi*lo;
+    // result(c) = acc_hi[c] + 2^-11 (acc_hi[c + 8] + acc_lo[c]).  Called for the finished plane AFTER the next step's barrier
+    // and BEFORE its prefetch: vmcnt counts loads and stores in order, so stores issued after the prefetch would sit between
+    // the loads and the wait that the next staging needs (the compiler then waits for the store round trip, vmcnt(0)).
+    // store offsets inside one output plane (bytes); OOB = dropped by the buffer store
+    unsigned yoff[2];
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        const int oy = y0 + 2 * rp + row;
+        yoff[row] = (col < 8 && oy < h) ? (unsigned)((((size_t)oy * w + x0 + 16 * xh + 4 * (lane >> 4)) * 8 + col) * 4) : OOB;
+    }
+    const int oxb = x0 + 16 * xh + 4 * (lane >> 4);
+    const size_t yplane_f = (size_t)h * w * 8;
+    auto emit = [&](int d, const sf32x4 (&a)[2][2]) {
+        const bool din = d >= dz0 && d < dz1;  // block-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            p.y + ((size_t)b * D + (din ? d : 0)) * yplane_f, 0, din ? (int)(yplane_f * 4) : 0, 0x00020000);
+        int ox = oxb;
+        asm volatile("" : "+v"(ox));  // opaque: keeps the eight store offsets from being hoisted into eight live VGPRs
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float hl = __shfl_down(a[row][0][i], 8, 16);
+                float r = a[row][0][i] + (hl + a[row][1][i]) * (1.0f / 2048.0f);
+                r = fmaf(r, esc_, esh_);
+                if (p.relu) r = fmaxf(r, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs, ox + i < w ? yoff[row] + 32u * i : OOB, 0, 0);
+            }
+        }
+    };
+
+    fetch(dz0 - 1);
+    asm volatile("" : "+v"(esc_), "+v"(esh_));  // the per-lane epilogue constants have landed: no vmcnt wait inside the loop
+    for (int z = dz0 - 1; z <= dz1; ++z) {  // input planes; outputs dz0 .. dz1-1
+        stash(z);
+        __syncthreads();  // also orders this step's writes of slot z&1 after the reads of step z-2
+        emit(z - 2, fin);
+        fetch(z + 1);
+        const char* slot = ring + (z & 1) * S_PLANE_BYTES;
+        // fragment i = (input row rr, kw, term): 24 per plane, reads pipelined DEPTH deep by hand
+        constexpr int NF = 24, DEPTH = 4;
         h16x8 fr[DEPTH];
         auto frag = [&](int i) {
-            const int term = i & 1, cg = (i >> 1) & 1, tap = i >> 2, kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
-            return *reinterpret_cast<const h16x8*>(slots[kd] + term * S_HALF_BYTES + fragk[kw] + (kh * S_COLS + cg * 16) * 64);
+            const int term = i & 1, kw = (i >> 1) % 3, rr = i / 6;
+            return *reinterpret_cast<const h16x8*>(slot + term * S_HALF_BYTES + fragk[kw] + rr * S_COLS * 64);
         };
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) fr[i] = frag(i);
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int i = tap * 4 + s4, term = s4 & 1, cg = s4 >> 1;
-                if (term == 0) acc1[cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[i % DEPTH], wf[tap], acc1[cg], 0, 0, 0);
-                else acc2[cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[i % DEPTH], wf[tap], acc2[cg], 0, 0, 0);
-                if (i + DEPTH < NP) fr[i % DEPTH] = frag(i + DEPTH);
+            for (int kt = 0; kt < 6; ++kt) {
+                const int i = rr * 6 + kt, term = kt & 1, kw = kt >> 1;
+                const h16x8 f = fr[i % DEPTH];
+#pragma unroll
+                for (int row = 0; row < 2; ++row) {
+                    const int kh = rr - row;
+                    if (kh < 0 || kh > 2) continue;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)  // plane slot s takes tap kd = 2 - s
+                        acc[s][row][term] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, wf[(2 - s) * 9 + kh * 3 + kw], acc[s][row][term], 0, 0, 0);
+                }
+                if (i + DEPTH < NF) fr[i % DEPTH] = frag(i + DEPTH);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // lane l holds rows (voxels) 4*(l/16) .. +3 of column l%16: columns 0..7 = hi*hi for cout c, columns 8..15 = hi*lo;
-        // result(c) = acc1[c] + 2^-11 (acc1[c + 8] + acc2[c])
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-            float r[4];
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float hl = __shfl_down(acc1[cg][i], 8, 16);
-                r[i] = acc1[cg][i] + (hl + acc2[cg][i]) * (1.0f / 2048.0f);
-                r[i] = fmaf(r[i], esc, esh);
-                if (p.relu) r[i] = fmaxf(r[i], 0.f);
+            for (int t = 0; t < 2; ++t) {
+                fin[r][t] = acc[0][r][t];
+                acc[0][r][t] = acc[1][r][t];
+                acc[1][r][t] = acc[2][r][t];
+                acc[2][r][t] = sf32x4{0, 0, 0, 0};
             }
-            if (col < 8 && oy < h) {
-                float* yrow = p.y + ((((size_t)b * D + d) * h + oy) * w) * 8 + col;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ox = x0 + cg * 16 + 4 * (lane >> 4) + i;
-                    if (ox < w) yrow[(size_t)ox * 8] = r[i];
-                }
-            }
-        }
-        __syncthreads();
     }
+    emit(dz1 - 1, fin);
 }
 
 }  // namespace mvd
@@ -213,7 +254,7 @@ int mvd_conv3d_bn_relu_f32_split(const float* x, const void* packed_w, const flo
     MVD_REQUIRE(x && packed_w && scale && shift && y, "conv3d_split: NULL argument");
     MVD_REQUIRE(Cin == 32 && Cout == 8, "conv3d_split: only the 32 -> 8 first layer of CostRegNet is built (got %d -> %d)", Cin, Cout);
     MVD_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "conv3d_split: non-positive dimension");
-    MVD_REQUIRE((long long)h * w * 32 < 0x7fffffffLL, "conv3d_split: one input plane exceeds the 32-bit offset range");
+    MVD_REQUIRE((long long)h * w * 128 < 0x7fffffffLL, "conv3d_split: one input plane exceeds the 31-bit byte-offset range");
     mvd::SplitParams p{};
     p.x = x; p.wpk = (const char*)packed_w; p.scale = scale; p.shift = shift; p.y = y;
     p.B = B; p.D = D; p.h = h; p.w = w; p.relu = relu;
@@ -227,7 +268,7 @@ int mvd_conv3d_bn_relu_f32_split(const float* x, const void* packed_w, const flo
     p.dgroups = (D + td - 1) / td;
     const long long nblk = 8LL * p.tiles_per_xcd * p.dgroups * B;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv3d_split: %lld workgroups exceed the grid limit", nblk);
-    const size_t lds = 3 * (size_t)mvd::S_PLANE_BYTES;
+    const size_t lds = 2 * (size_t)mvd::S_PLANE_BYTES + 256 * 16;  // two slots + the dump row
     (void)hipFuncSetAttribute((const void*)mvd::conv0_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mvd::conv0_split_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, p);
     return mvd::launch_status("conv3d_split");
