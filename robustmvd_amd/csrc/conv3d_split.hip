@@ -16,11 +16,20 @@
 // the two fp16 terms while it is staged (global -> registers -> LDS), all 27 weight fragments stay in registers.
 #include "mvd_common.h"
 
+// Knock-out / tuning macros for tools/ko_conv0_split.sh (timing only: the results of a knocked-out build are wrong).
+#ifndef SPLIT_KO
+#define SPLIT_KO 0  // 1 no reloads, 2 no stores, 4 no split + LDS writes, 8 no barrier, 16 no MFMAs, 32 no fragment reads
+#endif
+#ifndef SPLIT_DEPTH
+#define SPLIT_DEPTH 4
+#endif
+
 namespace mvd {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float sf32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int su32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int su32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int S_TH = 4, S_TW = 32, S_ROWS = S_TH + 2, S_COLS = S_TW + 2;
@@ -117,18 +126,33 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
         }
     };
     char* const dump = ring + 2 * S_PLANE_BYTES + tid * 16;
-    auto stash = [&](int d) {  // split into the two fp16 terms on the way into the LDS
+    // split two fp32 values into the packed fp16 pairs (hi, lo * 2^11): hi = fp16(a), t = a - hi (exact, mixed-precision fma
+    // straight from the packed half), lo = fp16(t * 2^11) written into its half.  5 instructions per pair; the compiler's own
+    // sequence for the same arithmetic is 10 (it converts every hi twice and back).
+    float k2048 = 2048.0f;
+    auto split2 = [k2048](float a0, float a1, unsigned& hi, unsigned& lo) {
+        unsigned hp, lp;
+        float t0, t1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a0), "v"(a1));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(hp), "v"(a0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(hp), "v"(a1));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(lp) : "v"(t0), "s"(k2048));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lp) : "v"(t1), "s"(k2048));
+        hi = hp;
+        lo = lp;
+    };
+    auto stash = [&](int d) {  // prologue only: the loop below stages inside the MFMA stream
         char* slot = ring + (d & 1) * S_PLANE_BYTES;
 #pragma unroll
         for (int k = 0; k < S_NLOAD; ++k) {
-            const sf32x4 a = __builtin_bit_cast(sf32x4, pre[k][0]), c = __builtin_bit_cast(sf32x4, pre[k][1]);
-            const _Float16 h0 = (_Float16)a.x, h1 = (_Float16)a.y, h2 = (_Float16)a.z, h3 = (_Float16)a.w;
-            const _Float16 h4 = (_Float16)c.x, h5 = (_Float16)c.y, h6 = (_Float16)c.z, h7 = (_Float16)c.w;
-            const su32x4 hv = {pack_h2(h0, h1), pack_h2(h2, h3), pack_h2(h4, h5), pack_h2(h6, h7)};
-            const su32x4 lv = {pack_h2((_Float16)((a.x - (float)h0) * 2048.0f), (_Float16)((a.y - (float)h1) * 2048.0f)),
-                               pack_h2((_Float16)((a.z - (float)h2) * 2048.0f), (_Float16)((a.w - (float)h3) * 2048.0f)),
-                               pack_h2((_Float16)((c.x - (float)h4) * 2048.0f), (_Float16)((c.y - (float)h5) * 2048.0f)),
-                               pack_h2((_Float16)((c.z - (float)h6) * 2048.0f), (_Float16)((c.w - (float)h7) * 2048.0f))};
+            su32x4 hv, lv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const sf32x4 v = __builtin_bit_cast(sf32x4, pre[k][q >> 1]);
+                unsigned hi, lo;
+                split2(v[(q & 1) * 2], v[(q & 1) * 2 + 1], hi, lo);
+                hv[q] = hi; lv[q] = lo;
+            }
             char* dst = loff[k] >= 0 ? slot + loff[k] : dump;
             *reinterpret_cast<su32x4*>(dst) = hv;
             *reinterpret_cast<su32x4*>(loff[k] >= 0 ? dst + S_HALF_BYTES : dst) = lv;
@@ -138,6 +162,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     // epilogue constants of the lanes that end up with a result: column (cout) l%16 < 8
     const int col = lane & 15;
     float esc_ = p.scale[col & 7], esh_ = p.shift[col & 7];
+    const float floor_ = p.relu ? 0.f : -__builtin_inff();
     const int xh = wv & 1, rp = wv >> 1;
 
     int fragk[3];
@@ -147,18 +172,13 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
         fragk[kw] = (2 * rp * S_COLS + c) * 64 + (((lane >> 4) ^ ((c >> 1) & 3)) * 16);
     }
 
-    // acc[plane slot][row][term]: slot 0 = output plane z-1 (finishes this step), 1 = plane z, 2 = plane z+1 (starts);
-    // fin = the plane that finished in the previous step, stored after this step's barrier
-    sf32x4 acc[3][2][2], fin[2][2];
+    // acc[plane slot][row][term]: slot 0 = output plane z-1 (finishes in this step), 1 = plane z, 2 = plane z+1 (starts)
+    sf32x4 acc[3][2][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int r = 0; r < 2; ++r) { acc[s][r][0] = sf32x4{0, 0, 0, 0}; acc[s][r][1] = sf32x4{0, 0, 0, 0}; }
 
-    // lane l holds voxels 4*(l/16) .. +3 of column l%16: columns 0..7 = hi*hi for cout c, columns 8..15 = hi*lo;
-    // result(c) = acc_hi[c] + 2^-11 (acc_hi[c + 8] + acc_lo[c]).  Called for the finished plane AFTER the next step's barrier
-    // and BEFORE its prefetch: vmcnt counts loads and stores in order, so stores issued after the prefetch would sit between
-    // the loads and the wait that the next staging needs (the compiler then waits for the store round trip, vmcnt(0)).
     // store offsets inside one output plane (bytes); OOB = dropped by the buffer store
     unsigned yoff[2];
 #pragma unroll
@@ -168,71 +188,118 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     }
     const int oxb = x0 + 16 * xh + 4 * (lane >> 4);
     const size_t yplane_f = (size_t)h * w * 8;
-    auto emit = [&](int d, const sf32x4 (&a)[2][2]) {
-        const bool din = d >= dz0 && d < dz1;  // block-uniform
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            p.y + ((size_t)b * D + (din ? d : 0)) * yplane_f, 0, din ? (int)(yplane_f * 4) : 0, 0x00020000);
-        int ox = oxb;
-        asm volatile("" : "+v"(ox));  // opaque: keeps the eight store offsets from being hoisted into eight live VGPRs
-#pragma unroll
-        for (int row = 0; row < 2; ++row) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float hl = __shfl_down(a[row][0][i], 8, 16);
-                float r = a[row][0][i] + (hl + a[row][1][i]) * (1.0f / 2048.0f);
-                r = fmaf(r, esc_, esh_);
-                if (p.relu) r = fmaxf(r, 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs, ox + i < w ? yoff[row] + 32u * i : OOB, 0, 0);
-            }
-        }
-    };
 
     fetch(dz0 - 1);
     asm volatile("" : "+v"(esc_), "+v"(esh_));  // the per-lane epilogue constants have landed: no vmcnt wait inside the loop
-    for (int z = dz0 - 1; z <= dz1; ++z) {  // input planes; outputs dz0 .. dz1-1
-        stash(z);
-        __syncthreads();  // also orders this step's writes of slot z&1 after the reads of step z-2
-        emit(z - 2, fin);
-        fetch(z + 1);
+    stash(dz0 - 1);
+    fetch(dz0);
+
+    // One step = one input plane z (outputs dz0 .. dz1-1 need z = dz0-1 .. dz1), ONE stream of 108 MFMAs in two passes over the
+    // plane's 24 fragments (fragment = input row rr, kw, term; rows 1 and 2, which feed both output rows, first):
+    //   pass A  tap kd = 2 only: finishes output plane z-1 (36 MFMAs)
+    //   pass B  taps kd = 1, 0 for planes z and z+1 (72 MFMAs); everything else rides between these MFMAs of the same wave,
+    //           where about two vector instructions per MFMA issue for free (tools/micro/coissue3.hip):
+    //           groups 0..7   epilogue + store of plane z-1 (one of the lane's 8 values per group)
+    //           groups 8..23  split item k = (g-8)/4 of plane z+1 (loaded a step ago), a pair of floats per group, write it to
+    //                         the other LDS slot, reload the item's registers with plane z+2
+    // so there is no staging phase, no copy of the finished accumulators and one barrier per step.  In a phase-separated
+    // version (stage, barrier, MFMAs, stores) the two workgroups of a CU ran in lockstep and the matrix pipe idled through
+    // every staging phase (50 % busy).
+    // With loads AND stores outstanding the compiler has to treat vmcnt as unordered: the first use of a prefetched register
+    // (pass B, group 8) becomes a full flush.  By then the youngest load is two thirds of a step old and the stores a full one.
+    for (int z = dz0 - 1; z <= dz1; ++z) {
+        if (!(SPLIT_KO & 8)) __syncthreads();  // plane z is staged; the other slot (plane z-1) has been read by every wave
         const char* slot = ring + (z & 1) * S_PLANE_BYTES;
-        // fragment i = (input row rr, kw, term): 24 per plane, reads pipelined DEPTH deep by hand
-        constexpr int NF = 24, DEPTH = 4;
+        char* wslot = ring + ((z + 1) & 1) * S_PLANE_BYTES;
+        const int din = z + 2, dout = z - 1;
+        const bool in_ok = din >= 0 && din < D && din <= dz1, out_ok = dout >= dz0 && dout < dz1;  // block-uniform
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xb + (in_ok ? (size_t)din * plane_f : 0)), 0, in_ok ? (int)(plane_f * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+            p.y + ((size_t)b * D + (out_ok ? dout : 0)) * yplane_f, 0, out_ok ? (int)(yplane_f * 4) : 0, 0x00020000);
+        int ox = oxb;
+        asm volatile("" : "+v"(ox));  // opaque: keeps the eight store offsets from being hoisted into eight live VGPRs
+
+        // read i = pass * 24 + fragment; reads pipelined DEPTH deep by hand
+        constexpr int NF = 24, NR = 2 * NF, DEPTH = SPLIT_DEPTH;
         h16x8 fr[DEPTH];
+        auto rr_of = [](int ro) { return ro == 0 ? 1 : ro == 1 ? 2 : ro == 2 ? 0 : 3; };
         auto frag = [&](int i) {
-            const int term = i & 1, kw = (i >> 1) % 3, rr = i / 6;
+            const int g = i % NF, term = g & 1, kw = (g >> 1) % 3, rr = rr_of(g / 6);
+            if (SPLIT_KO & 32) return wf[i % 27];
             return *reinterpret_cast<const h16x8*>(slot + term * S_HALF_BYTES + fragk[kw] + rr * S_COLS * 64);
         };
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) fr[i] = frag(i);
+        // ---- pass A
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
+        for (int g = 0; g < NF; ++g) {
+            const int term = g & 1, kw = (g >> 1) % 3, rr = rr_of(g / 6);
+            const h16x8 f = fr[g % DEPTH];
 #pragma unroll
-            for (int kt = 0; kt < 6; ++kt) {
-                const int i = rr * 6 + kt, term = kt & 1, kw = kt >> 1;
-                const h16x8 f = fr[i % DEPTH];
-#pragma unroll
-                for (int row = 0; row < 2; ++row) {
-                    const int kh = rr - row;
-                    if (kh < 0 || kh > 2) continue;
-#pragma unroll
-                    for (int s = 0; s < 3; ++s)  // plane slot s takes tap kd = 2 - s
-                        acc[s][row][term] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, wf[(2 - s) * 9 + kh * 3 + kw], acc[s][row][term], 0, 0, 0);
-                }
-                if (i + DEPTH < NF) fr[i % DEPTH] = frag(i + DEPTH);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int row = 0; row < 2; ++row) {
+                const int kh = rr - row;
+                if (kh < 0 || kh > 2) continue;
+                if (SPLIT_KO & 16) acc[0][row][term][0] += f[0] * wf[18 + kh * 3 + kw][0];
+                else acc[0][row][term] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, wf[18 + kh * 3 + kw], acc[0][row][term], 0, 0, 0);
             }
+            fr[g % DEPTH] = frag(g + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- pass B.  lane l holds voxels 4*(l/16) .. +3 of column l%16: columns 0..7 = hi*hi for cout c, columns 8..15 = hi*lo;
+        // result(c) = acc_hi[c] + 2^-11 (acc_hi[c + 8] + acc_lo[c])
+        float hl = __shfl_down(acc[0][0][0][0], 8, 16);
+        unsigned hq0 = 0, lq0 = 0;
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            const int term = g & 1, kw = (g >> 1) % 3, rr = rr_of(g / 6);
+            const h16x8 f = fr[(NF + g) % DEPTH];
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                const int kh = rr - row;
+                if (kh < 0 || kh > 2) continue;
+#pragma unroll
+                for (int s = 1; s < 3; ++s)  // plane slot s takes tap kd = 2 - s
+                    if (SPLIT_KO & 16) acc[s][row][term][0] += f[0] * wf[(2 - s) * 9 + kh * 3 + kw][0];
+                    else acc[s][row][term] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, wf[(2 - s) * 9 + kh * 3 + kw], acc[s][row][term], 0, 0, 0);
+            }
+            if (NF + g + DEPTH < NR) fr[(NF + g) % DEPTH] = frag(NF + g + DEPTH);
+            if (g < 8) {  // epilogue value g of the finished plane
+                const int row = g >> 2, i = g & 3;
+                const float cur = hl;
+                if (g + 1 < 8) hl = __shfl_down(acc[0][(g + 1) >> 2][0][(g + 1) & 3], 8, 16);
+                float r = __builtin_fmaf(cur + acc[0][row][1][i], 1.0f / 2048.0f, acc[0][row][0][i]);
+                r = fmaxf(__builtin_fmaf(r, esc_, esh_), floor_);
+                if (!(SPLIT_KO & 2) || r == 12345.678f)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs_out, ox + i < w ? yoff[row] + 32u * i : OOB, 0, 0);
+            } else if (!(SPLIT_KO & 4)) {  // staging of plane z+1 / reload with plane z+2: item k, float pair q of its 4
+                const int k = (g - 8) >> 2, q = (g - 8) & 3;
+                const sf32x4 v = __builtin_bit_cast(sf32x4, pre[k][q >> 1]);
+                unsigned hq1, lq1;
+                split2(v[(q & 1) * 2], v[(q & 1) * 2 + 1], hq1, lq1);
+                if (q & 1) {
+                    char* dst = (loff[k] >= 0 ? wslot + loff[k] : dump) + 8 * (q >> 1);
+                    *reinterpret_cast<su32x2*>(dst) = su32x2{hq0, hq1};
+                    *reinterpret_cast<su32x2*>(loff[k] >= 0 ? dst + S_HALF_BYTES : dst) = su32x2{lq0, lq1};
+                } else {
+                    hq0 = hq1; lq0 = lq1;
+                }
+                if (q == 3 && !(SPLIT_KO & 1)) {
+                    pre[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, gob[k], 0, 0);
+                    pre[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, gob[k] + 16u, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fin[r][t] = acc[0][r][t];
                 acc[0][r][t] = acc[1][r][t];
                 acc[1][r][t] = acc[2][r][t];
                 acc[2][r][t] = sf32x4{0, 0, 0, 0};
             }
     }
-    emit(dz1 - 1, fin);
 }
 
 }  // namespace mvd

@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from robustmvd_amd import ops, _lib as L
 CONFIGS = {1: (448, 640, 128), 2: (768, 1152, 256), 3: (896, 1216, 256)}
+if os.environ.get("MVD_ALT_LIB"):
+    L.use_experiments_library(os.environ["MVD_ALT_LIB"]).__enter__()
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 H, W, D = CONFIGS[cfg]
 h, w = H // 4, W // 4
