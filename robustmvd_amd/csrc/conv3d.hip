@@ -672,20 +672,21 @@ static int launch_march(const ConvParams& p0, hipStream_t st) {
 }
 
 // conv0 (32 -> 8, PAIR mode) with the reduction dimension split over TWO waves per output row: a workgroup is 8 waves —
-// waves 0-3 take input channels 0-15 of rows 0-3, waves 4-7 channels 16-31 — sharing one ring and one copy of the weights
-// in LDS.  conv3d_march_kernel runs this layer with ONE wave per SIMD (ring 78 KB + weights 74 KB fill the LDS), so every
-// barrier, ring store, epilogue and every vector-ALU instruction between MFMAs (which do not overlap with them on
-// gfx950, tools/micro/mfma_mix.hip) idles the matrix pipe: 69 % busy.  Two waves per SIMD fill each other's gaps.  The
-// second half's partial sums (one float4 per lane) go through LDS at the top of the next step, where a barrier exists
-// anyway.  Accumulation order: (channels 0-15 over all taps) + (channels 16-31 over all taps).
+// waves 0-3 take input channels 0-15 of rows 0-3, waves 4-7 channels 16-31 — sharing one ring.  conv3d_march_kernel runs
+// this layer with ONE wave per SIMD, so every barrier, ring store, epilogue and every vector-ALU instruction between MFMAs
+// (which do not overlap with them on gfx950, tools/micro/mfma_mix.hip) idles the matrix pipe: 69 % busy.  Two waves per SIMD
+// fill each other's gaps.  The second half's partial sums (one float4 per lane) go through LDS at the top of the next step,
+// where a barrier exists anyway.  Accumulation order: (channels 0-15 over all taps) + (channels 16-31 over all taps).
+// Each wave's 36 weight fragments live in registers (144 VGPRs; 233 in all, two waves per SIMD), the ring has FOUR slots.
+// Knock-out timings (round 2, 768x1152): the bare MFMA + fragment-read loop 2.01 ms (84 % of the fp32 matrix peak at 75 %
+// useful rows), ring write +0.10, the two barriers of the 3-slot form +0.06, epilogue +0.03, prefetch +0.03.
 template <int DZ>
 __global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
     constexpr int CIN = 32, TW = 16, SX = 2, ROWS = CONV_TH + 2, COLS = 2 * TW + 2, NWT = 4;
     constexpr int PSTR = CIN, SLAB = ROWS * COLS * PSTR, C4 = CIN / 4, NKG = 2;  // k-groups of 16 channels: one per wave half
     constexpr int NEL = ROWS * COLS * C4, NPF = (NEL + 511) / 512;
-    constexpr int WFLOATS = 36 * NKG * 64 * 4;
-    constexpr int DUMMY = 3 * SLAB / 4;  // float4 index of the dummy slot behind the ring
-    extern __shared__ __attribute__((aligned(16))) float ring[];  // [3][ROWS][COLS][PSTR] | dummy float4 | weights | partials
+    constexpr int DUMMY = 4 * SLAB / 4;  // float4 index of the dummy slot behind the ring
+    extern __shared__ __attribute__((aligned(16))) float ring[];  // [4][ROWS][COLS][PSTR] | dummy float4 | partials
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -740,13 +741,14 @@ __global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
         }
     };
 
-    float* __restrict__ wsrc = ring + 3 * SLAB + 4;
-    {
-        float4* __restrict__ wl4 = ring4 + DUMMY + 1;
-        const float4* __restrict__ wg4 = reinterpret_cast<const float4*>(p.wpk);
-        for (int e = tid; e < WFLOATS / 4; e += 512) wl4[e] = wg4[e];
-    }
-    float4* __restrict__ red4 = ring4 + DUMMY + 1 + WFLOATS / 4;  // [4 rows][64 lanes] partial sums of the second half
+    // LDS: [4 ring slots][dummy float4][partials of the second half, double-buffered by step parity]
+    float4* __restrict__ red4 = ring4 + DUMMY + 1;  // [2][4 rows][64 lanes]
+
+    // this wave's 36 weight fragments (its 16 channels x 16 rows x 36 taps) stay in registers: with the 74 KB weight copy out
+    // of the LDS the ring can hold a fourth plane, which is what takes the ring write out from between two barriers
+    float4 wreg[36];
+#pragma unroll
+    for (int t = 0; t < 36; ++t) wreg[t] = reinterpret_cast<const float4*>(p.wpk)[(t * NKG + kh_) * 64 + lane];
 
     float esc[4], esh[4];
 #pragma unroll
@@ -754,11 +756,14 @@ __global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
         esc[k] = p.scale[4 * (q & 1) + k];
         esh[k] = p.shift[4 * (q & 1) + k];
     }
+    // plane P lives in slot P & 3.  Before step z the ring holds z-1, z, z+1; plane z+2 is in flight in registers.
     load_plane(z0 - 1);
-    store_plane((z0 + 2) % 3);
+    store_plane((z0 - 1) & 3);
     load_plane(z0);
-    store_plane(z0 % 3);
+    store_plane(z0 & 3);
     load_plane(z0 + 1);
+    store_plane((z0 + 1) & 3);
+    load_plane(z0 + 2);
 
     // first half: its own partial sums of the previous plane, completed and stored at the top of the next step
     f32x4 mine = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -766,9 +771,9 @@ __global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
     const int orow = r0 + row;
     const int ocol = 2 * (c0 + vox) + (q >> 1);
     const bool live = orow < p.ho && ocol < p.wo;
-    auto finish_previous = [&]() {  // between the two barriers of a step (or after the last MFMAs + a barrier)
+    auto finish_previous = [&](int par) {  // after the barrier that follows the step whose partials sit in red4[par]
         if (kh_ == 0 && mine_p) {
-            const float4 o = red4[row * 64 + lane];
+            const float4 o = red4[(par * 4 + row) * 64 + lane];
             float r[4];
             const float a[4] = {mine[0] + o.x, mine[1] + o.y, mine[2] + o.z, mine[3] + o.w};
 #pragma unroll
@@ -780,19 +785,21 @@ __global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
         }
     };
 
+    // ONE barrier per step.  It publishes plane z+1 (written into its slot during step z-1) and the second half's partial
+    // sums of step z-1, and it retires every read of slot (z+2)&3 = (z-2)&3 (plane z-2, last read in step z-1), so that plane
+    // z+2 can be written into that slot in the MIDDLE of this step's MFMAs: the ring write is no longer a phase of its own
+    // between two barriers in which both waves of every SIMD leave the matrix pipe idle (knock-out timings of the 3-slot
+    // form: ring write 0.10 ms, second barrier 0.03 ms of 2.26).
     for (int z = z0; z < z1; ++z) {
-        __syncthreads();  // step z-1 no longer reads slot (z+1)%3; its second-half partials are in red4
-        store_plane((z + 1) % 3);
-        finish_previous();   // plane z-1: issued before this step's prefetch (vmcnt retires in order)
         __syncthreads();
-        load_plane(z + 2);   // lands during this step's MFMAs (unconditional, see conv3d_march_kernel)
+        finish_previous((z - 1) & 1);  // plane z-1: issued before this step's prefetch (vmcnt retires in order)
 
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
         auto read_group = [&](int step, int iw, float (&A)[NWT][4], float (&B)[NWT][4]) {
             const int kd = step / 3, kh = step - kd * 3;
-            const float* __restrict__ slab = ring + ((z + kd + 2) % 3) * SLAB;  // plane z + kd - 1
+            const float* __restrict__ slab = ring + ((z + kd - 1) & 3) * SLAB;  // plane z + kd - 1
             const int tap = step * 4 + iw;
-            const float4 ta = *reinterpret_cast<const float4*>(wsrc + ((tap * NKG + kh_) * 64 + lane) * 4);
+            const float4 ta = wreg[tap];
             A[iw][0] = ta.x; A[iw][1] = ta.y; A[iw][2] = ta.z; A[iw][3] = ta.w;
             const float* bp = slab + ((row + kh) * COLS + iw) * PSTR + (vox * SX) * PSTR +
                               (((kh_ * 4 + q) ^ ((vox + (iw >> 1)) & (C4 - 1)))) * 4;
@@ -817,6 +824,11 @@ __global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
                 mfma_group(iw, A0, B0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (step == 4) {  // two thirds of the step's MFMAs are issued: the plane loaded a step ago goes into the ring
+                store_plane((z + 2) & 3);
+                load_plane(z + 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (step + 1 < 9) {
 #pragma unroll
                 for (int iw = 0; iw < NWT; ++iw) {
@@ -828,21 +840,21 @@ __global__ void __launch_bounds__(512) conv0_ksplit_kernel(ConvParams p) {
         }
         acc += acc2;
         if (kh_ == 1) {
-            red4[row * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            red4[((z & 1) * 4 + row) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         } else {
             mine = acc;
             mine_p = live ? p.y + ((((size_t)b * p.Do + z) * p.ho + orow) * p.wo + ocol) * 8 + 4 * (q & 1) : nullptr;
         }
     }
     __syncthreads();
-    finish_previous();
+    finish_previous((z1 - 1) & 1);
 }
 
 template <int DZ>
 static int launch_conv0_ksplit(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
-    constexpr int ROWS = CONV_TH + 2, COLS = 34, SLAB = ROWS * COLS * 32, WFLOATS = 36 * 2 * 64 * 4;
-    constexpr size_t lds = (size_t)(3 * SLAB + 4 + WFLOATS + 4 * 64 * 4) * sizeof(float);
+    constexpr int ROWS = CONV_TH + 2, COLS = 34, SLAB = ROWS * COLS * 32;
+    constexpr size_t lds = (size_t)(4 * SLAB + 4 + 2 * 4 * 64 * 4) * sizeof(float);
     static_assert(lds <= 160 * 1024, "conv0 k-split: LDS");
     p.tiles_h = (p.ho + CONV_TH - 1) / CONV_TH;
     p.tiles_w = ((p.wo + 1) / 2 + 15) / 16;

@@ -13,7 +13,9 @@ ap = argparse.ArgumentParser(); ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--only", default="")
 ap.add_argument("--exp", action="store_true", help="route through lib_exp/libmvd_hip_exp.so (MVD_K4_* selectors apply)")
 args = ap.parse_args()
-if args.exp:
+if os.environ.get("MVD_ALT_LIB"):
+    L.use_experiments_library(os.environ["MVD_ALT_LIB"]).__enter__()
+elif args.exp:
     L.use_experiments_library().__enter__()
 H, W, V, D = CONFIGS[args.config]
 h, w = H // 4, W // 4
