@@ -12,6 +12,7 @@
 // Thread mapping: C/4 lanes per output pixel (each lane owns 4 channels = one 16-B load per tap),
 // 256/(C/4) consecutive x pixels per workgroup, one (b, d, y) row segment per workgroup.
 #include "mvd_common.h"
+#include <type_traits>
 #include "warp_variance_common.h"
 // knock-out builds (parts of the kernel removed to time the rest; they compute WRONG results) exist only in the
 // experiments library
@@ -733,12 +734,29 @@ __device__ __forceinline__ void gather_blend_4planes_2sets(float4 (&s1)[4], floa
     cell_step<MASK, 3>(s1, s2, w, X, Y, off, rsrc, rowb);
 }
 
+// Pipelined form: the first cell of this view (set X) was gathered while the PREVIOUS view was blended; the second cell (if
+// the chunk has one) is requested first thing, then the chain of cell_steps runs as above.
+template <int MASK, class TAP = u32x4>
+__device__ __forceinline__ void blend_view_prefetched(float4 (&s1)[4], float4 (&s2)[4], const float4* __restrict__ wl, TAP (&X)[4],
+                                                      TAP (&Y)[4], const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc,
+                                                      unsigned rowb) {
+    if constexpr (ncells_of(MASK) > 1) gather_cell_s(Y, rsrc, off[first_plane_of_cell(MASK, 1)], rowb);
+    const float4 w[4] = {wl[0], wl[32], wl[64], wl[96]};
+    cell_step<MASK, 0>(s1, s2, w, X, Y, off, rsrc, rowb);
+    cell_step<MASK, 1>(s1, s2, w, X, Y, off, rsrc, rowb);
+    cell_step<MASK, 2>(s1, s2, w, X, Y, off, rsrc, rowb);
+    cell_step<MASK, 3>(s1, s2, w, X, Y, off, rsrc, rowb);
+}
+
 // F16: features are fp16 zero-bordered channel-last maps (64 B per pixel), the volume is written as fp16 (B,D,h,w,32);
 // positions, weights, blend and variance stay fp32 (mvd_warp_variance_f16, BASELINE configs[3]).
 // WP (wave-private locate): every wave locates the 128 (pixel, plane, view) combinations of ITS OWN 8 pixels (2 per lane;
 // the two half-waves take even / odd views, so the transforms come from a small LDS table instead of the scalar cache) and
 // is the only reader of those table entries: no workgroup barrier inside the march, the four waves drift apart freely.
-template <int MINW, int NSETS, bool F16 = false, bool WP = false>
+// PIPE: views are software-pipelined.  A wave spends most of a (chunk, view) waiting for the view's first gather (vector ALU 46 %
+// busy, texture addresser 74 %, four waves per SIMD: profiles/r02_k3_march_pmc.txt); here the first cell of view v+1 is
+// requested before view v is blended, into a second pair of tap sets (64 tap VGPRs, three waves per SIMD).
+template <int MINW, int NSETS, bool F16 = false, bool WP = false, bool PIPE = false>
 __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpParams p, int nch) {
     constexpr int DPB = 4, PPB = 32;
     constexpr unsigned PIX = F16 ? 64 : 128;  // bytes per pixel
@@ -889,42 +907,89 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
 #pragma unroll
             for (int i = 0; i < DPB; ++i) { s1[i] = k; s2[i] = k2; }
         }
-        unsigned offn[DPB];
-        const char* srcn;
-        auto fetch_view = [&](int v) {
-            const unsigned* __restrict__ ol = offs + v * (DPB * PPB) + px;
+        if constexpr (PIPE) {
+            using TAP = typename std::conditional<F16, u32x2, u32x4>::type;
+            TAP X0[4], Y0[4], X1[4], Y1[4];
+            unsigned offa[DPB], offb[DPB], ma = 0, mb = 0;
+            __amdgpu_buffer_rsrc_t ra, rb;
+            // offsets + re-gather pattern of view v (wave-uniform mask), its descriptor, and the request for its first cell
+            auto open_view = [&](int v, unsigned (&off)[DPB], unsigned& mask, TAP (&X)[4]) {
+                const unsigned* __restrict__ ol = offs + v * (DPB * PPB) + px;
 #pragma unroll
-            for (int i = 0; i < DPB; ++i) offn[i] = ol[i * PPB];
-            srcn = reinterpret_cast<const char*>(p.src.p[v]);
-        };
-        fetch_view(0);
-        for (int v = 0; v < V; ++v) {
-            unsigned off[DPB];
-#pragma unroll
-            for (int i = 0; i < DPB; ++i) off[i] = offn[i] + org;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char*>(srcn + (size_t)b * img_bytes), 0, (int)img_bytes, 0x00020000);
-            const float4* __restrict__ wl = loc + v * (DPB * PPB) + px;
-            fetch_view(min(v + 1, V - 1));
-            const unsigned mask = (__builtin_amdgcn_ballot_w64(off[1] != off[0]) != 0 ? 1u : 0u) |
-                                  (__builtin_amdgcn_ballot_w64(off[2] != off[1]) != 0 ? 2u : 0u) |
-                                  (__builtin_amdgcn_ballot_w64(off[3] != off[2]) != 0 ? 4u : 0u);
-#define MVD_CASE(Mk)                                                                                   \
-    if constexpr (F16) gather_blend_4planes_2sets<Mk, u32x2>(s1, s2, wl, off, rsrc, rowb);             \
-    else if constexpr (NSETS == 2) gather_blend_4planes_2sets<Mk, u32x4>(s1, s2, wl, off, rsrc, rowb); \
-    else gather_blend_4planes_lds<Mk>(s1, s2, wl, off, rsrc, rowb);                                   \
-    break;
-            switch (mask) {
-                case 0: MVD_CASE(0)
-                case 1: MVD_CASE(1)
-                case 2: MVD_CASE(2)
-                case 3: MVD_CASE(3)
-                case 4: MVD_CASE(4)
-                case 5: MVD_CASE(5)
-                case 6: MVD_CASE(6)
-                default: MVD_CASE(7)
+                for (int i = 0; i < DPB; ++i) off[i] = ol[i * PPB] + org;
+                mask = (__builtin_amdgcn_ballot_w64(off[1] != off[0]) != 0 ? 1u : 0u) |
+                       (__builtin_amdgcn_ballot_w64(off[2] != off[1]) != 0 ? 2u : 0u) |
+                       (__builtin_amdgcn_ballot_w64(off[3] != off[2]) != 0 ? 4u : 0u);
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(reinterpret_cast<const char*>(p.src.p[v]) + (size_t)b * img_bytes), 0, (int)img_bytes, 0x00020000);
+                gather_cell_s(X, r, off[0], rowb);
+                return r;
+            };
+#define MVD_BLEND(Mk, Xs, Ys, offs_, rs_, v_) \
+    case Mk: blend_view_prefetched<Mk, TAP>(s1, s2, loc + (v_) * (DPB * PPB) + px, Xs, Ys, offs_, rs_, rowb); break;
+#define MVD_BLEND_ALL(mask_, Xs, Ys, offs_, rs_, v_)                                                                      \
+    switch (mask_) {                                                                                                     \
+        MVD_BLEND(0, Xs, Ys, offs_, rs_, v_) MVD_BLEND(1, Xs, Ys, offs_, rs_, v_) MVD_BLEND(2, Xs, Ys, offs_, rs_, v_)  \
+        MVD_BLEND(3, Xs, Ys, offs_, rs_, v_) MVD_BLEND(4, Xs, Ys, offs_, rs_, v_) MVD_BLEND(5, Xs, Ys, offs_, rs_, v_)  \
+        MVD_BLEND(6, Xs, Ys, offs_, rs_, v_)                                                                             \
+        default: blend_view_prefetched<7, TAP>(s1, s2, loc + (v_) * (DPB * PPB) + px, Xs, Ys, offs_, rs_, rowb); break;   \
+    }
+            // Every path between a request and the first use of its taps is straight-line code: behind a conditional request
+            // the compiler must assume the smaller number of outstanding loads and would wait for the prefetch it just issued.
+            ra = open_view(0, offa, ma, X0);
+            for (int v = 0; v + 1 < V; v += 2) {
+                rb = open_view(v + 1, offb, mb, X1);
+                MVD_BLEND_ALL(ma, X0, Y0, offa, ra, v)
+                if (v + 2 < V) {
+                    ra = open_view(v + 2, offa, ma, X0);
+                    MVD_BLEND_ALL(mb, X1, Y1, offb, rb, v + 1)
+                } else {
+                    MVD_BLEND_ALL(mb, X1, Y1, offb, rb, v + 1)
+                }
             }
-#undef MVD_CASE
+            if (V & 1) {  // the last view of an odd count was opened by the iteration before it (or above, V = 1)
+                MVD_BLEND_ALL(ma, X0, Y0, offa, ra, V - 1)
+            }
+#undef MVD_BLEND_ALL
+#undef MVD_BLEND
+        } else {
+            unsigned offn[DPB];
+            const char* srcn;
+            auto fetch_view = [&](int v) {
+                const unsigned* __restrict__ ol = offs + v * (DPB * PPB) + px;
+    #pragma unroll
+                for (int i = 0; i < DPB; ++i) offn[i] = ol[i * PPB];
+                srcn = reinterpret_cast<const char*>(p.src.p[v]);
+            };
+            fetch_view(0);
+            for (int v = 0; v < V; ++v) {
+                unsigned off[DPB];
+    #pragma unroll
+                for (int i = 0; i < DPB; ++i) off[i] = offn[i] + org;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(srcn + (size_t)b * img_bytes), 0, (int)img_bytes, 0x00020000);
+                const float4* __restrict__ wl = loc + v * (DPB * PPB) + px;
+                fetch_view(min(v + 1, V - 1));
+                const unsigned mask = (__builtin_amdgcn_ballot_w64(off[1] != off[0]) != 0 ? 1u : 0u) |
+                                      (__builtin_amdgcn_ballot_w64(off[2] != off[1]) != 0 ? 2u : 0u) |
+                                      (__builtin_amdgcn_ballot_w64(off[3] != off[2]) != 0 ? 4u : 0u);
+    #define MVD_CASE(Mk)                                                                                   \
+        if constexpr (F16) gather_blend_4planes_2sets<Mk, u32x2>(s1, s2, wl, off, rsrc, rowb);             \
+        else if constexpr (NSETS == 2) gather_blend_4planes_2sets<Mk, u32x4>(s1, s2, wl, off, rsrc, rowb); \
+        else gather_blend_4planes_lds<Mk>(s1, s2, wl, off, rsrc, rowb);                                   \
+        break;
+                switch (mask) {
+                    case 0: MVD_CASE(0)
+                    case 1: MVD_CASE(1)
+                    case 2: MVD_CASE(2)
+                    case 3: MVD_CASE(3)
+                    case 4: MVD_CASE(4)
+                    case 5: MVD_CASE(5)
+                    case 6: MVD_CASE(6)
+                    default: MVD_CASE(7)
+                }
+    #undef MVD_CASE
+            }
         }
         const int d0 = c * DPB;
 #pragma unroll
@@ -979,6 +1044,8 @@ static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int
         case 52: MVD_M(5, 2); break;
         case 62: MVD_M(6, 2); break;
         case 72: hipLaunchKernelGGL((warp_variance_march_kernel<4, 2, false, true>), grid, dim3(256), lds, st, p, nch); break;  // "M7,2,n": wave-private locate
+        case 82: hipLaunchKernelGGL((warp_variance_march_kernel<3, 2, false, false, true>), grid, dim3(256), lds, st, p, nch); break;  // "M8,2,n": views pipelined
+        case 92: hipLaunchKernelGGL((warp_variance_march_kernel<4, 2, false, false, true>), grid, dim3(256), lds, st, p, nch); break;  // "M9,2,n": views pipelined, 128 VGPRs
 #endif
         default: MVD_M(4, 2); break;
     }
