@@ -102,6 +102,18 @@ int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, c
                           float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
                           mvd_stream_t stream);
 
+/* The sweep of PlanesweepCorrelation(warp_only=True) — replaces WarpOnlyCorr.forward + warp_multi
+ *   rmvd/models/blocks/planesweep_corr.py:107-140, 13-45 (reached through correlate(), :514-521):
+ * the source features sampled at the S sweep positions of every key pixel (same grids as K1, :228-349, 489-512), times the
+ * SAMPLING mask ([sum of in-bounds tap weights >= 0.9999], :96-102; WarpOnlyCorr ignores the visibility mask it is handed).
+ * feat_src[v] (N,C,hs,ws); warped_out[v] (N,S,C,h,w); mask_out[v] (N,S,h,w).  normalize_after != 0: the warped features are
+ * L2-normalised along C, x / (|x| + 1e-9) (:8-10, 135-136), before the mask is applied.  invdepth_mode as in
+ * mvd_sweep_corr_ex_f32.  No workspace. */
+int mvd_sweep_warp_f32(const float* const* feat_src, const float* K_key, const float* const* K_src,
+                       const float* const* T_src2key, const float* invdepths, int invdepth_mode, int normalize_after, int N,
+                       int C, int h, int w, int hs, int ws, int S, int V, float* const* warped_out, float* const* mask_out,
+                       mvd_stream_t stream);
+
 /* K2 — replaces the view-weighting arithmetic of LearnedFusion.forward
  *   rmvd/models/blocks/learned_fusion.py:32-48 (softmax over views + 1e-9, mask-weighted mean, fused mask).
  * The per-view score maps (conv3x3+ReLU+conv1x1, :13-17,:28-30) are 2-D convolutions that stay on

@@ -208,6 +208,53 @@ def planesweep_correlation(feat_key, intrinsics_key, feat_sources, source_to_key
     return corrs, masks, inv_ret
 
 
+def sweep_warp_view(feat_src, us, vs, normalize=False):
+    """WarpOnlyCorr.forward (planesweep_corr.py:107-140) with warp_multi / warp (:13-104), zeros padding.
+    feat_src (N,C,hs,ws), us/vs (N,S,h,w) -> warped (N,S,C,h,w), mask (N,S,h,w).  The mask is the SAMPLING mask only: the
+    visibility mask that correlate() hands over (:515-517) is not used by this block."""
+    N, C, hs, ws = feat_src.shape
+    S, h, w = us.shape[1:]
+    if normalize == "before":
+        feat_src = (feat_src / (np.linalg.norm(feat_src, axis=1, keepdims=True) + F32(1e-9))).astype(F32)
+    out = np.zeros((N, S, C, h, w), F32)
+    mask = np.zeros((N, S, h, w), F32)
+    for n in range(N):
+        for s in range(S):
+            gx = F32(2.0) * us[n, s] / F32(ws) - F32(1.0)
+            gy = F32(2.0) * vs[n, s] / F32(hs) - F32(1.0)
+            ix, iy = unnormalize(gx, ws), unnormalize(gy, hs)
+            val = grid_sample_zeros(feat_src[n], ix, iy)  # (C,h,w)
+            inb_sum = np.zeros((h, w), F32)
+            for xi, yi, wgt, inb in bilinear_taps(ix, iy, hs, ws):
+                inb_sum += np.where(inb, wgt, F32(0.0))
+            m = np.where(inb_sum < F32(0.9999), F32(0.0), F32(1.0))
+            if normalize and normalize not in ("before", "dim"):  # True / "after": along C (:135-136)
+                val = (val / (np.linalg.norm(val, axis=0, keepdims=True) + F32(1e-9))).astype(F32)
+            out[n, s] = val * m[None]
+            mask[n, s] = m
+    return out, mask
+
+
+def planesweep_warp(feat_key_size, intrinsics_key, feat_sources, source_to_key_transforms, sampling_invdepths,
+                    intrinsics_sources=None, normalize=False):
+    """PlanesweepCorrelation(warp_only=True).forward, planesweep_corr.py:396-427 + 514-521: (warped[V], masks[V])."""
+    h, w = feat_key_size
+    N = feat_sources[0].shape[0]
+    if intrinsics_sources is None:
+        intrinsics_sources = [intrinsics_key] * len(feat_sources)
+    inv = np.asarray(sampling_invdepths, F32)
+    per_pixel = inv.ndim == 4 and (inv.shape[2] > 1 or inv.shape[3] > 1)
+    inv_n = np.broadcast_to(inv, (N, inv.shape[1], h, w)) if per_pixel else np.broadcast_to(inv.reshape(inv.shape[0], inv.shape[1]), (N, inv.shape[1]))
+    outs, masks = [], []
+    for fs, T, Ks in zip(feat_sources, source_to_key_transforms, intrinsics_sources):
+        co = epipolar_coeffs(intrinsics_key, Ks, T, h, w, fs.shape[2], fs.shape[3])
+        us, vs, _vis = sweep_grids(co, inv_n)
+        o, m = sweep_warp_view(fs, us, vs, normalize)
+        outs.append(o)
+        masks.append(m)
+    return outs, masks
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0):
     """Plain NCHW 2-D cross-correlation (used for the fusion score convs only)."""
     N, C, H, W = x.shape

@@ -46,13 +46,14 @@ class PlanesweepCorrelation(nn.Module):
     def __init__(self, warp_only=False, normalize="dim"):
         """normalize (TorchCorr, planesweep_corr.py:142-189): "dim" divides the dot products by sqrt(C) (what robust_mvd
         uses); True / "before" L2-normalises both feature maps along C first (x / (|x| + 1e-9), :8-10); False leaves
-        the raw dot products.  warp_only=True (WarpOnlyCorr, :106-139: returns the warped source FEATURES instead of
-        correlations) is used by no model of the reference and is not built."""
+        the raw dot products.  warp_only=True (WarpOnlyCorr, :106-139) returns the warped source FEATURES (N,S,C,h,w) and
+        the sampling mask instead of correlations; there "before" normalises the source features first, True / "after" the
+        warped ones along C, "dim" / False nothing (:128-136).  Inference only."""
         super().__init__()
-        if warp_only:
-            raise NotImplementedError("warp_only=True (WarpOnlyCorr) is used by no registered model and is not built")
-        if normalize not in ("dim", "before", True, False):
-            raise ValueError(f"normalize={normalize!r}: expected 'dim', 'before', True or False")
+        self.warp_only = bool(warp_only)
+        allowed = ("dim", "before", "after", True, False) if warp_only else ("dim", "before", True, False)
+        if normalize not in allowed:
+            raise ValueError(f"normalize={normalize!r}: expected one of {allowed}")
         self.normalize = normalize
         self._invdepth_cache = {}  # (num, min, max, type, device) -> device tensor: constants of the model, uploaded once
 
@@ -73,6 +74,11 @@ class PlanesweepCorrelation(nn.Module):
         sampling grids and masks are constants in both (the reference computes them under no_grad, :436,464,489)."""
         args = (feat_key, intrinsics_key, feat_sources, source_to_key_transforms, intrinsics_sources, num_sampling_points,
                 min_depth, max_depth, sampling_invdepths, sampling_type)
+        if self.warp_only:
+            if ops.needs_grad(feat_sources):
+                raise ValueError("PlanesweepCorrelation(warp_only=True) has no backward in this engine: detach the features")
+            with torch.no_grad():
+                return self._forward(None, *args)
         if ops.needs_grad(feat_key, feat_sources):
             return self._forward(ops.sweep_corr_autograd, *args)
         with torch.no_grad():
@@ -107,6 +113,21 @@ class PlanesweepCorrelation(nn.Module):
             inv = inv.reshape(inv.shape[0], inv.shape[1])
         else:  # per key pixel: (N,S,H,1) or (N,S,H,W), batch broadcast like the reference's arithmetic would
             inv = inv.expand(feat_key.shape[0], inv.shape[1], feat_key.shape[2], feat_key.shape[3]).contiguous()
+        if self.warp_only:
+            srcs = list(feat_sources)
+            if self.normalize == "before":
+                srcs = [f / (torch.linalg.norm(f, dim=1, keepdim=True) + 1e-9) for f in srcs]
+            after = self.normalize is True or self.normalize == "after"
+            warped, masks = [None] * len(srcs), [None] * len(srcs)
+            groups = {}
+            for i, f in enumerate(srcs):
+                groups.setdefault(tuple(f.shape[-2:]), []).append(i)
+            for idxs in groups.values():
+                wv, mv = ops.sweep_warp([srcs[i] for i in idxs], intrinsics_key, [intrinsics_sources[i] for i in idxs],
+                                        [source_to_key_transforms[i] for i in idxs], inv, feat_key.shape[-2:], after)
+                for i, wi, mi in zip(idxs, wv, mv):
+                    warped[i], masks[i] = wi, mi
+            return warped, masks, inv_out
         corr_scale = None  # 1/sqrt(C)
         if self.normalize != "dim":
             corr_scale = 1.0

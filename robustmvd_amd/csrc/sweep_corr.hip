@@ -254,6 +254,72 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
     }
 }
 
+// WarpOnlyCorr (planesweep_corr.py:107-140): the plane sweep without the correlation — the source features sampled at the
+// S positions of every key pixel, times the sampling mask.  Same grids and mask as sweep_corr_kernel; source features in the
+// caller's own (N,C,hs,ws) layout (one thread per (plane, key pixel) walks the channels, so neighbouring threads read
+// neighbouring source pixels of one channel plane and write neighbouring outputs).  norm_after: normalize(warped, dim=C)
+// = x / (|x|_2 + 1e-9) (:8-10,135-136) before the mask is applied.  Output (N,S,C,h,w), mask (N,S,h,w).
+struct WarpOnlyParams {
+    ViewPtrs src;    // V x (N,C,hs,ws)
+    ViewPtrs K_src;  // V x (N,3,3)
+    ViewPtrs T;      // V x (N,4,4)
+    ViewOutPtrs out; // V x (N,S,C,h,w)
+    ViewOutPtrs mask;
+    const float* K_key;
+    const float* invd;
+    int invd_stride, invd_per_pixel, norm_after;
+    int N, C, h, w, hs, ws, S, V;
+};
+
+__global__ void __launch_bounds__(256) sweep_warp_kernel(WarpOnlyParams p) {
+    const int h = p.h, w = p.w, hs = p.hs, ws = p.ws, S = p.S, C = p.C;
+    const int v = blockIdx.z % p.V, n = blockIdx.z / p.V;
+    const int s = blockIdx.y;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (long long)h * w) return;
+    const int y = (int)(pix / w), x = (int)(pix - (long long)y * w);
+    const Epi E = epipolar(p.K_key + n * 9, p.K_src.p[v] + n * 9, p.T.p[v] + n * 16, h, w, hs, ws);
+    const float xc = (float)x + 0.5f, yc = (float)y + 0.5f;
+    const float u_inf = (E.a * xc + E.b * yc) + E.c;
+    const float v_inf = (E.f * xc + E.g * yc) + E.h;
+    const float k_inf = (E.j * xc + E.k * yc) + E.l;
+    const float z_pole = -(E.m / k_inf);
+    const float ds = p.invd_per_pixel ? p.invd[(((size_t)n * S + s) * h + y) * w + x] : p.invd[(size_t)n * p.invd_stride + s];
+    const float den = k_inf + E.m * ds;
+    const float us = replace_nonfinite((u_inf + E.e * ds) / den);
+    const float vs = replace_nonfinite((v_inf + E.i * ds) / den);
+    const float zs = 1.0f / ds;
+    const bool visible = (zs > 0.f) && (((k_inf > 0.f) && (zs > z_pole)) || ((k_inf < 0.f) && (zs < z_pole)) ||
+                                       ((k_inf == 0.f) && (E.m > 0.f)));
+    const float fws = (float)ws, fhs = (float)hs;
+    const float ix = unnormalize_coord(2.0f * us / fws - 1.0f, fws);
+    const float iy = unnormalize_coord(2.0f * vs / fhs - 1.0f, fhs);
+    const Taps t = bilinear_taps(ix, iy, hs, ws);
+    // WarpOnlyCorr does not take the visibility mask (its forward is called with grids only, :131-133, the `mask`
+    // argument is unused): the returned mask is the sampling mask alone
+    (void)visible;
+    const float mk = t.inb < 0.9999f ? 0.f : 1.f;
+    const size_t plane = (size_t)hs * ws;
+    const float* __restrict__ sp = p.src.p[v] + (size_t)n * C * plane;
+    float scale = mk;
+    if (p.norm_after) {
+        float ss = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* q = sp + (size_t)c * plane;
+            const float val = fmaf(q[t.off[3]], t.w[3], fmaf(q[t.off[2]], t.w[2], fmaf(q[t.off[1]], t.w[1], q[t.off[0]] * t.w[0])));
+            ss = fmaf(val, val, ss);
+        }
+        scale = mk / (sqrtf(ss) + 1e-9f);
+    }
+    float* __restrict__ op = p.out.p[v] + (((size_t)n * S + s) * C) * ((size_t)h * w) + pix;
+    for (int c = 0; c < C; ++c) {
+        const float* q = sp + (size_t)c * plane;
+        const float val = fmaf(q[t.off[3]], t.w[3], fmaf(q[t.off[2]], t.w[2], fmaf(q[t.off[1]], t.w[1], q[t.off[0]] * t.w[0])));
+        op[(size_t)c * h * w] = val * scale;
+    }
+    p.mask.p[v][((size_t)n * S + s) * ((size_t)h * w) + pix] = mk;
+}
+
 int transpose_launch(const float* src, float* dst, int N, long long rows, long long cols, hipStream_t st);
 int repack_padded_launch(const float* src, float* dst, int B, int C, int h, int w, hipStream_t st);
 size_t padded_slot_bytes_public(int B, int C, int h, int w);
@@ -339,5 +405,32 @@ int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, c
     }
     mvd::timing_end(st);
     return mvd::launch_status("sweep_corr");
+}
+int mvd_sweep_warp_f32(const float* const* feat_src, const float* K_key, const float* const* K_src,
+                       const float* const* T_src2key, const float* invdepths, int invdepth_mode, int normalize_after, int N,
+                       int C, int h, int w, int hs, int ws, int S, int V, float* const* warped_out, float* const* mask_out,
+                       mvd_stream_t stream) {
+    MVD_REQUIRE(invdepth_mode == MVD_INVDEPTH_SHARED || invdepth_mode == MVD_INVDEPTH_BATCHED || invdepth_mode == MVD_INVDEPTH_PER_PIXEL,
+                "sweep_warp: invdepth_mode %d", invdepth_mode);
+    MVD_REQUIRE(feat_src && K_key && K_src && T_src2key && invdepths && warped_out && mask_out, "sweep_warp: NULL argument");
+    MVD_REQUIRE(N > 0 && C > 0 && h > 0 && w > 0 && hs > 0 && ws > 0 && S > 0, "sweep_warp: non-positive dimension");
+    MVD_REQUIRE(V >= 1 && V <= MVD_MAX_VIEWS, "sweep_warp: V=%d outside 1..%d", V, MVD_MAX_VIEWS);
+    MVD_REQUIRE(S <= 65535 && (long long)N * V <= 65535, "sweep_warp: S or N*V exceeds 65535");
+    MVD_REQUIRE((long long)hs * ws < 0x7fffffffLL, "sweep_warp: source map %dx%d too large", hs, ws);
+    mvd::WarpOnlyParams p{};
+    for (int v = 0; v < V; ++v) {
+        MVD_REQUIRE(feat_src[v] && K_src[v] && T_src2key[v] && warped_out[v] && mask_out[v], "sweep_warp: NULL view %d", v);
+        p.src.p[v] = feat_src[v]; p.K_src.p[v] = K_src[v]; p.T.p[v] = T_src2key[v];
+        p.out.p[v] = warped_out[v]; p.mask.p[v] = mask_out[v];
+    }
+    p.K_key = K_key; p.invd = invdepths;
+    p.invd_stride = invdepth_mode == MVD_INVDEPTH_BATCHED ? S : 0;
+    p.invd_per_pixel = invdepth_mode == MVD_INVDEPTH_PER_PIXEL;
+    p.norm_after = normalize_after ? 1 : 0;
+    p.N = N; p.C = C; p.h = h; p.w = w; p.hs = hs; p.ws = ws; p.S = S; p.V = V;
+    const long long npix = (long long)h * w;
+    dim3 grid((unsigned)((npix + 255) / 256), (unsigned)S, (unsigned)(N * V));
+    hipLaunchKernelGGL(mvd::sweep_warp_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return mvd::launch_status("sweep_warp");
 }
 }

@@ -99,6 +99,40 @@ def sweep_corr(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths, c
 
 
 @inference_only
+def sweep_warp(feat_sources, K_key, K_sources, T_src2key, invdepths, key_size, normalize_after=False):
+    """WarpOnlyCorr's sweep (planesweep_corr.py:107-140).  feat_sources V x (N,C,hs,ws); key_size (h, w) of the key feature
+    map; invdepths as in sweep_corr.  Returns (warped[V] (N,S,C,h,w), masks[V] (N,S,h,w))."""
+    lib = L.load()
+    srcs = _views(feat_sources, "feat_sources")
+    V = len(srcs)
+    s0 = L.as_f32(srcs[0], "feat_sources[0]")
+    if s0.dim() != 4:
+        raise ValueError("feat_sources must be (N,C,hs,ws)")
+    N, C, hs, ws = s0.shape
+    dev = s0.device
+    h, w = int(key_size[0]), int(key_size[1])
+    srcs = [L.as_f32(s, f"feat_sources[{i}]", (N, C, hs, ws), dev) for i, s in enumerate(srcs)]
+    Kk = L.as_f32(K_key, "intrinsics_key", (N, 3, 3), dev)
+    Ks = [L.as_f32(k, f"intrinsics_sources[{i}]", (N, 3, 3), dev) for i, k in enumerate(_views(K_sources, "intrinsics_sources", V))]
+    Ts = [L.as_f32(t, f"source_to_key_transforms[{i}]", (N, 4, 4), dev) for i, t in enumerate(_views(T_src2key, "source_to_key_transforms", V))]
+    inv = L.as_f32(invdepths, "sampling_invdepths", device=dev)
+    mode = _invdepth_mode(inv, N, h, w)
+    S = inv.shape[1]
+    outs = [torch.empty((N, S, C, h, w), dtype=torch.float32, device=dev) for _ in range(V)]
+    masks = [torch.empty((N, S, h, w), dtype=torch.float32, device=dev) for _ in range(V)]
+    a_src, k1 = L.ptr_array(srcs)
+    a_K, k2 = L.ptr_array(Ks)
+    a_T, k3 = L.ptr_array(Ts)
+    a_o, k4 = L.ptr_array(outs)
+    a_m, k5 = L.ptr_array(masks)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_sweep_warp_f32(a_src, L.ptr(Kk), a_K, a_T, L.ptr(inv), mode, 1 if normalize_after else 0,
+                                    N, C, h, w, hs, ws, S, V, a_o, a_m, L.stream_of(s0))
+    L.check(rc, "mvd_sweep_warp_f32")
+    return outs, masks
+
+
+@inference_only
 def fuse_views(corrs, masks, scores):
     """K2. corrs, masks V x (N,S,h,w); scores V x (N,1,h,w) -> fused, fused_mask (N,S,h,w)."""
     lib = L.load()

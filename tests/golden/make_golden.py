@@ -509,7 +509,27 @@ def g12():
     save("g12_sweep_options", **out)
 
 
+def g13():
+    """PlanesweepCorrelation(warp_only=True) (WarpOnlyCorr, planesweep_corr.py:107-140): warped source features and sampling
+    masks for normalize in (False, "before", True).  C = 16, key and sources 12x18 (warp_multi reshapes the result to the SOURCE size, :33-43, so the reference itself only runs with equal sizes), S = 6."""
+    K_px, T_sd = sample_data_calib()
+    K_rel = (K_px / np.array([[1280.0] * 3, [720.0] * 3, [1.0] * 3], np.float32))[None]
+    fk = gc.rng_array(1501, (1, 16, 12, 18))
+    fs = [gc.rng_array(1502, (1, 16, 12, 18)), gc.rng_array(1503, (1, 16, 12, 18))]
+    Ts = [T_sd[0][None], T_sd[3][None]]
+    out = {"K": K_rel, "T0": Ts[0], "T1": Ts[1]}
+    for name, norm in (("none", False), ("before", "before"), ("after", True)):
+        blk = ref.planesweep_corr.PlanesweepCorrelation(warp_only=True, normalize=norm)
+        warped, masks, invd = blk(feat_key=t(fk), intrinsics_key=t(K_rel), feat_sources=[t(f) for f in fs],
+                                  source_to_key_transforms=[t(T) for T in Ts], num_sampling_points=6, min_depth=0.4, max_depth=1000.0)
+        for v in range(2):
+            out[f"{name}_warped{v}"] = warped[v].numpy()
+            out[f"{name}_mask{v}"] = np.packbits(masks[v].numpy().astype(np.uint8).ravel())
+    out["invdepths"] = invd.numpy()
+    save("g13_warp_only", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for g in which:
         globals()[g]()

@@ -8,6 +8,7 @@ import torch
 
 import gen_common as gc
 from conftest import load_golden, unpack_mask
+from oracle import mvd_oracle as O
 from test_oracle_golden import (_sweep_inputs, check_sweep_outputs, costreg_shapes, featurenet_shapes, fusion_inputs,
                                 fusion_weights)
 
@@ -346,7 +347,7 @@ def test_mvsnet_end_to_end_golden(dev):
 @pytest.mark.parametrize("name,norm", [("none", False), ("before", "before"), ("pp", "dim")])
 def test_sweep_block_options_golden(name, norm, dev):
     """PlanesweepCorrelation(normalize=False / "before") and per-key-pixel sampling inverse depths (N,S,H,W) against
-    the reference block's outputs (g12); warp_only stays unbuilt (used by no model of the reference)."""
+    the reference block's outputs (g12)."""
     import robustmvd_amd as R
     g = load_golden("g12_sweep_options")
     fk = T(gc.rng_array(1401, (1, 64, 12, 18)), dev)
@@ -362,8 +363,42 @@ def test_sweep_block_options_golden(name, norm, dev):
         assert (m != ref_m).mean() <= 1e-3
         ok = m == ref_m
         np.testing.assert_allclose(corrs[v].cpu().numpy()[ok], ref_c[ok], atol=ATOL, rtol=RTOL)
-    with pytest.raises(NotImplementedError):
-        R.PlanesweepCorrelation(warp_only=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,norm", [("none", False), ("before", "before"), ("after", True)])
+def test_warp_only_block_golden(name, norm, dev):
+    """PlanesweepCorrelation(warp_only=True) (WarpOnlyCorr, planesweep_corr.py:107-140) against the reference block's
+    outputs (g13), plus what the reference cannot run: sources of another size than the key map (against the oracle)."""
+    import robustmvd_amd as R
+    g = load_golden("g13_warp_only")
+    fk = T(gc.rng_array(1501, (1, 16, 12, 18)), dev)
+    fs_np = [gc.rng_array(1502, (1, 16, 12, 18)), gc.rng_array(1503, (1, 16, 12, 18))]
+    blk = R.PlanesweepCorrelation(warp_only=True, normalize=norm)
+    Ts = [T(g["T0"], dev), T(g["T1"], dev)]
+    warped, masks, inv = blk(fk, T(g["K"], dev), [T(f, dev) for f in fs_np], Ts, num_sampling_points=6, min_depth=0.4, max_depth=1000.0)
+    np.testing.assert_allclose(inv.cpu().numpy(), g["invdepths"], rtol=1e-6)
+    for v in range(2):
+        ref_w = g[f"{name}_warped{v}"]
+        ref_m = unpack_mask(g[f"{name}_mask{v}"], (1, 6, 12, 18))
+        m = masks[v].cpu().numpy()
+        assert tuple(warped[v].shape) == (1, 6, 16, 12, 18)
+        assert (m != ref_m).mean() <= 1e-3
+        ok = np.broadcast_to((m == ref_m)[:, :, None], ref_w.shape)
+        np.testing.assert_allclose(warped[v].cpu().numpy()[ok], ref_w[ok], atol=ATOL, rtol=RTOL)
+    # a smaller source map, two batch elements with their own inverse depths
+    rng = np.random.default_rng(5)
+    fs2 = [rng.standard_normal((2, 16, 10, 14)).astype(np.float32)]
+    K2 = np.repeat(g["K"], 2, 0); T2 = np.repeat(g["T1"], 2, 0)
+    inv2 = np.stack([g["invdepths"].reshape(-1), g["invdepths"].reshape(-1) * 0.7]).astype(np.float32)
+    w_o, m_o = O.planesweep_warp((12, 18), K2, fs2, [T2], inv2, normalize=norm)
+    w_h, m_h, _ = blk(T(np.zeros((2, 16, 12, 18), np.float32), dev), T(K2, dev), [T(fs2[0], dev)], [T(T2, dev)], sampling_invdepths=T(inv2, dev))
+    mh = m_h[0].cpu().numpy()
+    assert (mh != m_o[0]).mean() <= 1e-3
+    ok = np.broadcast_to((mh == m_o[0])[:, :, None], w_o[0].shape)
+    np.testing.assert_allclose(w_h[0].cpu().numpy()[ok], w_o[0][ok], atol=ATOL, rtol=RTOL)
+    with pytest.raises(ValueError):
+        blk(fk, T(g["K"], dev), [T(fs_np[0], dev).requires_grad_()], Ts[:1], num_sampling_points=6, min_depth=0.4, max_depth=1000.0)
 
 
 def test_pinned_uploader_matches_direct_upload(dev):

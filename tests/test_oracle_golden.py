@@ -368,3 +368,20 @@ def test_g12_sweep_block_options(name, norm):
         assert (masks[v] != ref_m).mean() <= 1e-3
         ok = masks[v] == ref_m
         np.testing.assert_allclose(corrs[v][ok], ref_c[ok], atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("name,norm", [("none", False), ("before", "before"), ("after", True)])
+def test_g13_warp_only_block(name, norm):
+    """PlanesweepCorrelation(warp_only=True) = WarpOnlyCorr (planesweep_corr.py:107-140): warped source features (N,S,C,h,w)
+    and the sampling mask, for the block's three normalisation modes"""
+    g = load_golden("g13_warp_only")
+    fs = [gc.rng_array(1502, (1, 16, 12, 18)), gc.rng_array(1503, (1, 16, 12, 18))]
+    warped, masks = O.planesweep_warp((12, 18), g["K"], fs, [g["T0"], g["T1"]], g["invdepths"], normalize=norm)
+    for v in range(2):
+        ref_w = g[f"{name}_warped{v}"]
+        ref_m = unpack_mask(g[f"{name}_mask{v}"], (1, 6, 12, 18))
+        assert warped[v].shape == ref_w.shape == (1, 6, 16, 12, 18)
+        assert (masks[v] != ref_m).mean() <= 1e-3
+        ok = np.broadcast_to((masks[v] == ref_m)[:, :, None], ref_w.shape)
+        np.testing.assert_allclose(warped[v][ok], ref_w[ok], atol=ATOL, rtol=RTOL)
+        assert ref_m.sum() > 0 and (ref_m == 0).sum() > 0  # the fixture exercises both mask values
