@@ -70,7 +70,11 @@ __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
     for (int t = 0; t < 27; ++t) wf[t] = *reinterpret_cast<const f16x8*>(p.wpk + ((size_t)t * 64 + lane) * 16);
 
     // ---- staging map of this thread: chunk e = tid + 256 k -> (row, col, 16-byte chunk) of the tile + halo ----
-    int goff[C0_NLOAD];       // byte offset inside a plane of x, or -1 (outside the image / beyond the tile)
+    // Everything on the memory side is branch-free: a voxel outside the image (or a plane outside the volume) is an
+    // out-of-range buffer offset (reads 0), rows / columns beyond the output are out-of-range store offsets (dropped).  Behind
+    // exec-masked branches the compiler cannot count outstanding operations and waits vmcnt(0), stores included.
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned goff[C0_NLOAD];  // byte offset inside a plane of x, or OOB
     int loff[C0_NLOAD];       // byte offset inside a ring slot
 #pragma unroll
     for (int k = 0; k < C0_NLOAD; ++k) {
@@ -79,35 +83,59 @@ __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
         const int r = vox / C0_COLS, c = vox - r * C0_COLS;
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
         const bool in = e < C0_PLANE_CHUNKS && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        goff[k] = in ? ((gy * w + gx) * 64 + ch * 16) : -1;
+        goff[k] = in ? (unsigned)((gy * w + gx) * 64 + ch * 16) : OOB;
         // the four 16-byte channel chunks of a voxel are XOR-swizzled by the voxel-pair index of its column: a fragment read
         // (16 consecutive voxels x 4 chunks, serviced in the four 16-lane groups of ds_read_b128) then touches every bank
         // once instead of twice (enumerated over all alignments; plain 64-B pitch: two-way conflicts everywhere)
-        loff[k] = e < C0_PLANE_CHUNKS ? (vox * 64 + ((ch ^ ((c >> 1) & 3)) * 16)) : -1;
+        loff[k] = e < C0_PLANE_CHUNKS ? (vox * 64 + ((ch ^ ((c >> 1) & 3)) * 16)) : 3 * C0_PLANE_BYTES + tid * 16;  // else: dump row
     }
     const size_t plane_bytes = (size_t)h * w * 64;
     const char* xb = p.x + (size_t)b * D * plane_bytes;
     u32x4v pre[C0_NLOAD];
     auto fetch = [&](int d) {  // plane d of the input tile -> registers (zeros outside the volume)
         const bool din = d >= 0 && d < D;  // block-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(xb + (din ? (size_t)d * plane_bytes : 0)), 0, din ? (int)plane_bytes : 0, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < C0_NLOAD; ++k) {
-            pre[k] = u32x4v{0, 0, 0, 0};
-            if (din && goff[k] >= 0) pre[k] = *reinterpret_cast<const u32x4v*>(xb + (size_t)d * plane_bytes + goff[k]);
-        }
+        for (int k = 0; k < C0_NLOAD; ++k) pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[k], 0, 0);
     };
     auto stash = [&](int d) {  // registers -> ring slot of plane d
         char* slot = ring + ((d + 3) % 3) * C0_PLANE_BYTES;
 #pragma unroll
         for (int k = 0; k < C0_NLOAD; ++k)
-            if (loff[k] >= 0) *reinterpret_cast<u32x4v*>(slot + loff[k]) = pre[k];
+            *reinterpret_cast<u32x4v*>(loff[k] < 3 * C0_PLANE_BYTES ? slot + loff[k] : ring + loff[k]) = pre[k];
     };
 
     // per-lane epilogue constants: couts 4*(lane/16) .. +3 (lanes 32..63 hold the padding rows 8..15)
     const int cq = (lane >> 4) & 1;
     const float4 sc = reinterpret_cast<const float4*>(p.scale)[cq], sh = reinterpret_cast<const float4*>(p.shift)[cq];
     const int oy = y0 + wv;
-    const bool row_ok = oy < h && lane < 32;
+    // store offsets inside one output plane (bytes), OOB = dropped
+    unsigned yoff[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+        const int ox = x0 + cg * 16 + (lane & 15);
+        yoff[cg] = (oy < h && lane < 32 && ox < w) ? (unsigned)((((size_t)oy * w + ox) * 8 + cq * 4) * 4) : OOB;
+    }
+    const size_t yplane = (size_t)h * w * 8;
+    f32x4 fin[4];  // the plane finished in the previous step: stored after this step's first barrier, BEFORE its prefetch —
+                   // vmcnt retires in order, so stores issued behind the prefetch would sit between the loads and the wait
+                   // the next staging needs
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) fin[cg] = f32x4{0, 0, 0, 0};
+    auto emit = [&](int d) {
+        const bool ok = d >= dz0 && d < dz1;  // block-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            p.y + ((size_t)b * D + (ok ? d : 0)) * yplane, 0, ok ? (int)(yplane * 4) : 0, 0x00020000);
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            float r0 = fmaf(fin[cg][0], sc.x, sh.x), r1 = fmaf(fin[cg][1], sc.y, sh.y), r2 = fmaf(fin[cg][2], sc.z, sh.z),
+                  r3 = fmaf(fin[cg][3], sc.w, sh.w);
+            if (p.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4v{__float_as_uint(r0), __float_as_uint(r1), __float_as_uint(r2), __float_as_uint(r3)},
+                                                   rs, yoff[cg], 0, 0);
+        }
+    };
 
     fetch(dz0 - 1); stash(dz0 - 1);
     fetch(dz0);     stash(dz0);
@@ -124,6 +152,7 @@ __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
     for (int d = dz0; d < dz1; ++d) {
         stash(d + 1);
         __syncthreads();          // planes d-1, d, d+1 are in the ring
+        emit(d - 1);
         fetch(d + 2);             // flies under the MFMAs below
         f32x4 acc[4];
 #pragma unroll
@@ -147,21 +176,11 @@ __global__ void __launch_bounds__(256, 2) conv0_f16_kernel(Conv0Params p) {
             if (i + DEPTH < NP) fr[i % DEPTH] = frag(i + DEPTH);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (row_ok) {
-            float* yrow = p.y + ((((size_t)b * D + d) * h + oy) * w) * 8 + cq * 4;
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
-                const int ox = x0 + cg * 16 + (lane & 15);
-                if (ox < w) {
-                    float4 r = make_float4(fmaf(acc[cg][0], sc.x, sh.x), fmaf(acc[cg][1], sc.y, sh.y),
-                                           fmaf(acc[cg][2], sc.z, sh.z), fmaf(acc[cg][3], sc.w, sh.w));
-                    if (p.relu) r = make_float4(fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f));
-                    *reinterpret_cast<float4*>(yrow + (size_t)ox * 8) = r;
-                }
-            }
-        }
+        for (int cg = 0; cg < 4; ++cg) fin[cg] = acc[cg];
         __syncthreads();          // every wave is done with plane d-1: its slot takes plane d+2 next iteration
     }
+    emit(dz1 - 1);
 }
 
 }  // namespace mvd
@@ -198,7 +217,7 @@ int mvd_conv3d_bn_relu_f16in(const void* x, const void* packed_w, const float* s
     p.dgroups = (D + td - 1) / td;
     const long long nblk = 8LL * p.tiles_per_xcd * p.dgroups * B;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv3d_f16in: %lld workgroups exceed the grid limit", nblk);
-    const size_t lds = 3 * (size_t)mvd::C0_PLANE_BYTES;
+    const size_t lds = 3 * (size_t)mvd::C0_PLANE_BYTES + 256 * 16;  // ring + the dump row of the idle staging lanes
     (void)hipFuncSetAttribute((const void*)mvd::conv0_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mvd::conv0_f16_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, p);
     return mvd::launch_status("conv3d_f16in");
