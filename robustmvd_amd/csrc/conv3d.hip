@@ -1436,6 +1436,12 @@ static int launch_conv_best(const ConvParams& p, hipStream_t st) {
 template <int CIN, int NT, int MTMAX>
 static int launch_march_best(const ConvParams& p, hipStream_t st) {
     if constexpr (MTMAX >= 4) {
+#ifdef MVD_EXPERIMENTS
+        if (const char* e = exp_env("MVD_K4_MARCH_MT")) {  // forced tile width (narrower tiles = more workgroups per CU): conv2
+            if (atoi(e) == 1) return launch_march<CIN, NT, 1, false>(p, st);  // 0.267 (3) / 0.271 (2) / 0.247 ms (1)
+            if (atoi(e) == 2) return launch_march<CIN, NT, 2, false>(p, st);
+        }
+#endif
         if (best_mt(p.wo, 3, 4) == 3) return launch_march<CIN, NT, 3, false>(p, st);
     }
     return launch_march<CIN, NT, MTMAX, false>(p, st);
