@@ -497,7 +497,15 @@ __device__ __forceinline__ void blend_plane_lds(float4 (&s1)[4], float4 (&s2)[4]
 
 // taps of one cell: nw at `o`, ne at +128 (folds into the instruction's immediate), sw / se one padded row further
 // (the row pitch rides in the scalar offset operand: no per-lane address arithmetic besides `o` itself)
+#ifndef MVD_K3_KO
+#define MVD_K3_KO 0  // knock-out builds of the marching kernel (tools/ko_k3.sh; wrong results): 2 no gathers, 4 no stores, 1 no locate
+#endif
 __device__ __forceinline__ void gather_cell_s(u32x4 (&f)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned o, unsigned rowb) {
+    if constexpr ((MVD_K3_KO & 2) != 0) {
+        f[0] = u32x4{o, o + 1, o + 2, o + 3}; f[1] = u32x4{o + 4, o + 5, o + 6, o + 7};
+        f[2] = u32x4{o + rowb, o + 9, o + 10, o + 11}; f[3] = u32x4{o + rowb + 4, o + 13, o + 14, o + 15};
+        return;
+    }
     f[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
     f[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 128u, 0, 0);
     f[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, rowb, 0);
@@ -706,9 +714,16 @@ __device__ __forceinline__ void blend_if_cell(float4 (&s1)[4], float4 (&s2)[4], 
     if constexpr (cell_of(MASK, I) == K) blend_plane_lds<MASK, I>(s1, s2, w[I], (K & 1) ? Y : X);
 }
 
-template <int MASK, int K, class TAP>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// `after_last_gather` runs right behind the LAST gather request of the view (the parked stores of the previous chunk go there:
+// every later wait of this view is for loads that are OLDER than those stores)
+template <int MASK, int K, class TAP, class Hook = NoHook>
 __device__ __forceinline__ void cell_step(float4 (&s1)[4], float4 (&s2)[4], const float4 (&w)[4], TAP (&X)[4], TAP (&Y)[4],
-                                          const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb) {
+                                          const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb,
+                                          const Hook& after_last_gather = Hook()) {
     if constexpr (K < ncells_of(MASK)) {
         blend_if_cell<MASK, K, 0>(s1, s2, w, X, Y);
         blend_if_cell<MASK, K, 1>(s1, s2, w, X, Y);
@@ -717,21 +732,30 @@ __device__ __forceinline__ void cell_step(float4 (&s1)[4], float4 (&s2)[4], cons
         if constexpr (K + 2 < ncells_of(MASK)) {  // the set this cell just released takes the cell after next
             __builtin_amdgcn_sched_barrier(0);    // (left alone, the scheduler hoists these loads above the blends and spills)
             gather_cell_s((K & 1) ? Y : X, rsrc, off[first_plane_of_cell(MASK, K + 2)], rowb);
+            if constexpr (K + 2 == ncells_of(MASK) - 1) {
+                after_last_gather();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }
 
-template <int MASK, class TAP = u32x4>
+template <int MASK, class TAP = u32x4, class Hook = NoHook>
 __device__ __forceinline__ void gather_blend_4planes_2sets(float4 (&s1)[4], float4 (&s2)[4], const float4* __restrict__ wl,
-                                                           const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb) {
+                                                           const unsigned (&off)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned rowb,
+                                                           const Hook& after_last_gather = Hook()) {
     TAP X[4], Y[4];
     gather_cell_s(X, rsrc, off[0], rowb);
     if constexpr (ncells_of(MASK) > 1) gather_cell_s(Y, rsrc, off[first_plane_of_cell(MASK, 1)], rowb);
+    if constexpr (ncells_of(MASK) <= 2) {
+        after_last_gather();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     const float4 w[4] = {wl[0], wl[32], wl[64], wl[96]};
-    cell_step<MASK, 0>(s1, s2, w, X, Y, off, rsrc, rowb);
-    cell_step<MASK, 1>(s1, s2, w, X, Y, off, rsrc, rowb);
-    cell_step<MASK, 2>(s1, s2, w, X, Y, off, rsrc, rowb);
-    cell_step<MASK, 3>(s1, s2, w, X, Y, off, rsrc, rowb);
+    cell_step<MASK, 0>(s1, s2, w, X, Y, off, rsrc, rowb, after_last_gather);
+    cell_step<MASK, 1>(s1, s2, w, X, Y, off, rsrc, rowb, after_last_gather);
+    cell_step<MASK, 2>(s1, s2, w, X, Y, off, rsrc, rowb, after_last_gather);
+    cell_step<MASK, 3>(s1, s2, w, X, Y, off, rsrc, rowb, after_last_gather);
 }
 
 // Pipelined form: the first cell of this view (set X) was gathered while the PREVIOUS view was blended; the second cell (if
@@ -756,7 +780,12 @@ __device__ __forceinline__ void blend_view_prefetched(float4 (&s1)[4], float4 (&
 // PIPE: views are software-pipelined.  A wave spends most of a (chunk, view) waiting for the view's first gather (vector ALU 46 %
 // busy, texture addresser 74 %, four waves per SIMD: profiles/r02_k3_march_pmc.txt); here the first cell of view v+1 is
 // requested before view v is blended, into a second pair of tap sets (64 tap VGPRs, three waves per SIMD).
-template <int MINW, int NSETS, bool F16 = false, bool WP = false, bool PIPE = false>
+// PARK (needs WP): a chunk's results are not stored at its end but parked in LDS (16 KB, wave-private) and stored from the
+// middle of the NEXT chunk's first view, right behind that view's last gather request.  vmcnt retires loads and stores in one
+// order: stores issued at the end of a chunk sit in front of the next chunk's first gathers, and the first blend then waits for
+// their write acknowledgements (knock-out timings, profiles/r02_k3_march_ko.txt: no stores -0.10 ms, no gathers -0.12 ms,
+// neither -0.25 ms of 0.72).
+template <int MINW, int NSETS, bool F16 = false, bool WP = false, bool PIPE = false, bool PARK = false>
 __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpParams p, int nch) {
     constexpr int DPB = 4, PPB = 32;
     constexpr unsigned PIX = F16 ? 64 : 128;  // bytes per pixel
@@ -764,6 +793,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
     extern __shared__ __attribute__((aligned(16))) float4 lds_raw[];  // 2 x ([V][4][32] float4 weights + [V][4][32] u32 offsets)
     const int V = p.V;
     const int half_q = V * (DPB * PPB) * 5 / 4;  // float4 slots per table half (weights + offsets)
+    constexpr int NH = (WP && PARK) ? 1 : 2;     // table halves in the allocation (the wave-private locate uses one)
 
     const int tid = threadIdx.x;
     const int h = p.h, w = p.w, D = p.D;
@@ -799,7 +829,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
     const float W2f = (float)W2;
     const int v_first = __builtin_amdgcn_readfirstlane(tid >> 7);
     // wave-private form: lane = (pixel of this wave l&7, plane (l>>3)&3, view parity l>>5)
-    float4* __restrict__ mtab = lds_raw + 2 * half_q + 256;  // [V][3] float4: the composed transforms (WP only)
+    float4* __restrict__ mtab = lds_raw + NH * half_q + 256;  // [V][3] float4: the composed transforms (WP only)
     if constexpr (WP) {
         if (tid < V * 3) {
             cfloat* Mg = (cfloat*)(p.M + ((size_t)(tid / 3) * p.B + b) * 12 + (tid % 3) * 4);
@@ -846,7 +876,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
         const float e0 = dvals[min(d0, D - 1)], e1 = dvals[min(d0 + 1, D - 1)], e2 = dvals[min(d0 + 2, D - 1)],
                     e3 = dvals[min(d0 + 3, D - 1)];
         const float depth = li == 0 ? e0 : li == 1 ? e1 : li == 2 ? e2 : e3;
-        for (int v = v_first; v < V; v += 2) {
+        for (int v = v_first; v < ((MVD_K3_KO & 1) ? 0 : V); v += 2) {
             cfloat* M = (cfloat*)(p.M + ((size_t)v * p.B + b) * 12);  // scalar loads
             const float ax = fmaf(M[0], lfx, fmaf(M[1], lfy, M[2]));
             const float ay = fmaf(M[4], lfx, fmaf(M[5], lfy, M[6]));
@@ -870,7 +900,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
     const int xc = min(x0 + px, w - 1);
     const unsigned org = rowb + PIX + (unsigned)q * QB;  // padded (1,1) + this lane's channel quad
     // the key features of this thread's (pixel, channel quad) stay in LDS between chunks (4 fewer long-lived VGPRs)
-    float4* __restrict__ key_slot = lds_raw + 2 * half_q + tid;
+    float4* __restrict__ key_slot = lds_raw + NH * half_q + tid;
     {
         const char* kp = reinterpret_cast<const char*>(p.key) + (size_t)b * img_bytes + org + (unsigned)y * rowb + (unsigned)xc * PIX;
         if constexpr (F16) {
@@ -887,6 +917,28 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
     // branch around the stores
     const unsigned out_off = ((unsigned)y * (unsigned)w + (unsigned)xc) * PIX + (unsigned)q * QB;
     const size_t plane_bytes = (size_t)h * w * PIX;
+    // PARK: [4 planes][256 lanes] float4 behind the transforms; each lane reads back what it wrote
+    float4* __restrict__ park_base = lds_raw + NH * half_q + 256 + ((V * 3 + 3) & ~3);
+    int parked_d0 = -1;  // first plane of the chunk whose results are parked (wave-uniform)
+    auto drain = [&]() {
+        if (parked_d0 < 0) return;
+        // the kernel sits exactly at 128 VGPRs: lane-derived addresses are recomputed from an opaque copy of the thread index
+        // and the planes leave one at a time (4 VGPRs in flight)
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const unsigned oo = ((unsigned)y * (unsigned)w + (unsigned)min(x0 + (t_ >> 3), w - 1)) * PIX + (unsigned)(t_ & 7) * QB;
+        const float4* __restrict__ pk = park_base + t_;
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) {
+            const float4 r = pk[i * 256];
+            const int d = min(parked_d0 + i, D - 1);
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<char*>(p.out) + ((size_t)b * D + d) * plane_bytes, 0, parked_d0 + i < D ? (int)plane_bytes : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z),
+                                                         __float_as_uint(r.w)}, orsrc, oo, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 
     if constexpr (WP) __syncthreads();  // transforms and key slots are staged; no further workgroup barrier
     else locate(c_begin, 0);
@@ -978,16 +1030,33 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
         else if constexpr (NSETS == 2) gather_blend_4planes_2sets<Mk, u32x4>(s1, s2, wl, off, rsrc, rowb); \
         else gather_blend_4planes_lds<Mk>(s1, s2, wl, off, rsrc, rowb);                                   \
         break;
-                switch (mask) {
-                    case 0: MVD_CASE(0)
-                    case 1: MVD_CASE(1)
-                    case 2: MVD_CASE(2)
-                    case 3: MVD_CASE(3)
-                    case 4: MVD_CASE(4)
-                    case 5: MVD_CASE(5)
-                    case 6: MVD_CASE(6)
-                    default: MVD_CASE(7)
+    #define MVD_CASE_HOOK(Mk) gather_blend_4planes_2sets<Mk, u32x4>(s1, s2, wl, off, rsrc, rowb, drain_v0); break;
+                if constexpr (PARK) {  // the previous chunk's parked results leave behind the first view's last gather request
+                    const bool first = v == 0;  // wave-uniform
+                    auto drain_v0 = [&]() { if (first) drain(); };
+                    switch (mask) {
+                        case 0: MVD_CASE_HOOK(0)
+                        case 1: MVD_CASE_HOOK(1)
+                        case 2: MVD_CASE_HOOK(2)
+                        case 3: MVD_CASE_HOOK(3)
+                        case 4: MVD_CASE_HOOK(4)
+                        case 5: MVD_CASE_HOOK(5)
+                        case 6: MVD_CASE_HOOK(6)
+                        default: MVD_CASE_HOOK(7)
+                    }
+                } else {
+                    switch (mask) {
+                        case 0: MVD_CASE(0)
+                        case 1: MVD_CASE(1)
+                        case 2: MVD_CASE(2)
+                        case 3: MVD_CASE(3)
+                        case 4: MVD_CASE(4)
+                        case 5: MVD_CASE(5)
+                        case 6: MVD_CASE(6)
+                        default: MVD_CASE(7)
+                    }
                 }
+    #undef MVD_CASE_HOOK
     #undef MVD_CASE
             }
         }
@@ -998,17 +1067,24 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
             const float mx = s1[i].x * inv_nv, my = s1[i].y * inv_nv, mz = s1[i].z * inv_nv, mw = s1[i].w * inv_nv;
             const float4 r = make_float4(fmaf(s2[i].x, inv_nv, -mx * mx), fmaf(s2[i].y, inv_nv, -my * my),
                                          fmaf(s2[i].z, inv_nv, -mz * mz), fmaf(s2[i].w, inv_nv, -mw * mw));
+            if constexpr (PARK) {
+                park_base[i * 256 + tid] = r;
+                continue;
+            }
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
                 reinterpret_cast<char*>(p.out) + ((size_t)b * D + d0 + i) * plane_bytes, 0, (int)plane_bytes, 0x00020000);
             if constexpr (F16) {  // round to nearest even, one rounding
                 const f16x2 lo = {(_Float16)r.x, (_Float16)r.y}, hi = {(_Float16)r.z, (_Float16)r.w};
                 store_b64(u32x2{as_u32(lo), as_u32(hi)}, orsrc, out_off);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z),
-                                                             __float_as_uint(r.w)}, orsrc, out_off, 0, 0);
+                if ((MVD_K3_KO & 4) == 0 || r.x == 123.456f)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z),
+                                                                 __float_as_uint(r.w)}, orsrc, out_off, 0, 0);
             }
         }
+        if constexpr (PARK) parked_d0 = d0;
     }
+    if constexpr (PARK) drain();
 }
 
 static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int nsets, int nch, bool f16 = false) {
@@ -1046,6 +1122,8 @@ static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int
         case 72: hipLaunchKernelGGL((warp_variance_march_kernel<4, 2, false, true>), grid, dim3(256), lds, st, p, nch); break;  // "M7,2,n": wave-private locate
         case 82: hipLaunchKernelGGL((warp_variance_march_kernel<3, 2, false, false, true>), grid, dim3(256), lds, st, p, nch); break;  // "M8,2,n": views pipelined
         case 92: hipLaunchKernelGGL((warp_variance_march_kernel<4, 2, false, false, true>), grid, dim3(256), lds, st, p, nch); break;  // "M9,2,n": views pipelined, 128 VGPRs
+        case 102: hipLaunchKernelGGL((warp_variance_march_kernel<4, 2, false, true, false, true>), grid, dim3(256), lds + 4 * 256 * sizeof(float4) + 64, st, p, nch); break;  // "M10,2,n": wave-private locate + parked stores
+        case 112: hipLaunchKernelGGL((warp_variance_march_kernel<3, 2, false, true, false, true>), grid, dim3(256), lds + 4 * 256 * sizeof(float4) + 64, st, p, nch); break;  // "M11,2,n": the same at three waves per SIMD
 #endif
         default: MVD_M(4, 2); break;
     }

@@ -52,8 +52,10 @@ def main():
     import contextlib
     for cfg in args.cfgs:
       # "product" = the shipped library (fixed dispatch); anything else = a variant of the experiments library
-      with (contextlib.nullcontext() if cfg == "product" else L.use_experiments_library()):
-        os.environ["MVD_K3_CFG"] = cfg
+      # "lib:<path>" = an alternate library (knock-out builds of tools/ko_k3.sh)
+      alt = cfg[4:] if cfg.startswith("lib:") else None
+      with (contextlib.nullcontext() if cfg == "product" else L.use_experiments_library(alt)):
+        os.environ["MVD_K3_CFG"] = "" if alt else cfg
         lib = L.load()
         for _ in range(3):
             out = ops.warp_variance(feats[0], feats[1:], projs, key_inv, depth, channels_last=cl)
@@ -71,7 +73,7 @@ def main():
             diff = 0.0
         else:
             diff = float((out - ref).abs().max())
-        print(f"cfg {cfg:>5s} layout {args.layout}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s  (min {min(ts):.3f})  maxdiff_vs_first {diff:.2e}",
+        print(f"cfg {os.path.basename(cfg):>5s} layout {args.layout}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s  (min {min(ts):.3f})  maxdiff_vs_first {diff:.2e}",
               flush=True)
         del out
 
