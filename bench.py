@@ -331,6 +331,38 @@ def main():
 
     if extras and not half:
         guarded("conv0_split_operands", split_block)
+
+    def mfma_roofline_block():
+        """Second roofline block: the LONGEST kernel of the step, the regulariser's first layer (K4 conv0: 3x3x3, 32 -> 8,
+        fp32 MFMA), against the fp32 matrix peak.  Timed standalone (torch events around 10 back-to-back launches on a volume
+        of the step's shape) after the timed region; the per-launch time agrees with its row in the rocprofv3 kernel stats."""
+        from robustmvd_amd import ops
+        from robustmvd_amd import _lib as L
+        h4, w4 = H // 4, W // 4
+        reg = model.cost_regularization
+        wgt, cin, cout, sc, sh, mode = reg._prepare()["conv0"]
+        x = torch.randn(1, D, h4, w4, 32, device=dev)
+        for _ in range(3):
+            y = ops.conv3d_bn_relu(x, wgt, cin, cout, sc, sh, mode, relu=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 10
+        e0.record()
+        for _ in range(n):
+            y = ops.conv3d_bn_relu(x, wgt, cin, cout, sc, sh, mode, relu=True)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / n
+        flops = 2.0 * 27 * 32 * 8 * D * h4 * w4
+        out["roofline_mfma"] = {"bound": "mfma", "kernel": "conv3d first layer (K4 conv0, 32->8, 3x3x3)", "achieved": flops / ms / 1e9,
+                                "peak": 157.3, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / 157.3,
+                                "algorithmic_flops_per_launch": flops, "avg_launch_ms": ms, "launches_timed": n,
+                                "note": "dense fp32 MFMA peak (MI355X_MICROARCH.md); 8 output channels fill at most 75 % of the "
+                                        "16 MFMA rows (DESIGN.md K4), so 0.75 is this layer's ceiling; timed standalone after the "
+                                        "timed region"}
+        del x, y
+
+    if extras and not half:
+        guarded("roofline_mfma", mfma_roofline_block)
     del samples
     torch.cuda.empty_cache()
 
