@@ -269,9 +269,9 @@ def main():
                             "note": "same workload and step count, two HIP streams per process; not the headline value"}
 
     # Multi-rank runs (the driver's scaling curve) measure the headline only: every extra block below contains barriers, so
-    # a failure on ONE rank would hang the others and lose the whole line.  MVD_BENCH_EXTRAS=1 forces all of them on;
+    # a failure on ONE rank would hang the others and lose the whole line.  MVD_BENCH_EXTRAS=1 forces all of them on, =0 turns them off at one rank too (clean kernel statistics under rocprofv3);
     # --include-h2d adds just the h2d_inclusive block (what SURVEY.md 8(e) expects to limit 1 -> 8 GPU scaling).
-    extras = world == 1 or os.environ.get("MVD_BENCH_EXTRAS", "0") == "1"
+    extras = (world == 1 and os.environ.get("MVD_BENCH_EXTRAS", "") != "0") or os.environ.get("MVD_BENCH_EXTRAS", "0") == "1"
     if extras and os.environ.get("MVD_BENCH_PIPELINED", "1") == "1":
         guarded("pipelined", pipelined_block)
 
