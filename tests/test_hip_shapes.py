@@ -158,6 +158,14 @@ def test_conv0_marching_large_grid_vs_oracle(dev):
     y = ops.conv3d_bn_relu(T(x, dev).permute(0, 2, 3, 4, 1).contiguous(), packed, Cin, Cout, T(scale, dev), T(shift, dev), 0)
     np.testing.assert_allclose(y.permute(0, 4, 1, 2, 3).cpu().numpy(), ref, atol=ATOL, rtol=RTOL)
     del x, ref, y
+    # the same kernel with TWO batch elements (2 x 24 x 12 x 2 = 1152 workgroups of 8 planes; the batch index is the slowest
+    # part of its block decode)
+    B2, D2b, h2b, w2b = 2, 96, 96, 64
+    xb = rng.standard_normal((B2, Cin, D2b, h2b, w2b)).astype(np.float32)
+    refb = np.stack([CO.conv3d(xb[b], wgt, scale, shift) for b in range(B2)])
+    yb = ops.conv3d_bn_relu(T(xb, dev).permute(0, 2, 3, 4, 1).contiguous(), packed, Cin, Cout, T(scale, dev), T(shift, dev), 0)
+    np.testing.assert_allclose(yb.permute(0, 4, 1, 2, 3).cpu().numpy(), refb, atol=ATOL, rtol=RTOL)
+    del xb, refb, yb
     # 16 -> 16 (conv2's form): 2 x 16 x 33 = 1056 workgroups of 8 planes
     D2, h2, w2 = 264, 64, 100
     x16 = rng.standard_normal((1, 16, D2, h2, w2)).astype(np.float32)
