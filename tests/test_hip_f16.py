@@ -158,3 +158,25 @@ def test_mvsnet_conv0_split_matches_default_model(dev):
     p0, _ = m0.run(**kw)
     p1, _ = m1.run(**kw)
     np.testing.assert_allclose(p1["depth"], p0["depth"], rtol=1e-5)
+
+
+def test_conv0_f16_and_split_batch_of_two(dev):
+    """both MFMA-fp16 forms of conv0 on TWO batch elements with a ragged tile grid and two plane groups per element
+    (the batch index is the slowest part of their block decode), against the C oracle per element"""
+    from robustmvd_amd import ops
+    rng = np.random.default_rng(77)
+    B, D, h, w = 2, 40, 10, 70
+    wt = (rng.standard_normal((8, 32, 3, 3, 3)) * np.sqrt(2 / (32 * 27))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 8).astype(np.float32)
+    shift = (rng.standard_normal(8) * 0.1).astype(np.float32)
+    x = rng.standard_normal((B, 32, D, h, w)).astype(np.float32)
+    xt = T(x, dev).permute(0, 2, 3, 4, 1).contiguous()
+    got = ops.conv3d_bn_relu_split(xt, ops.pack_conv3d_weights_split(T(wt, dev)), T(scale, dev), T(shift, dev))
+    ref = np.stack([CO.conv3d(x[b], wt, scale, shift, stride=1, relu=True) for b in range(B)])
+    np.testing.assert_allclose(got.permute(0, 4, 1, 2, 3).cpu().numpy(), ref, atol=1e-4, rtol=1e-4)
+    x16 = x.astype(np.float16)
+    got16 = ops.conv3d_bn_relu_f16in(T(x16, dev).permute(0, 2, 3, 4, 1).contiguous(), ops.pack_conv3d_weights_f16(T(wt, dev)),
+                                     T(scale, dev), T(shift, dev))
+    ref16 = np.stack([CO.conv3d(x16[b].astype(np.float32), wt.astype(np.float16).astype(np.float32), scale, shift, stride=1, relu=True)
+                      for b in range(B)])
+    np.testing.assert_allclose(got16.permute(0, 4, 1, 2, 3).cpu().numpy(), ref16, atol=1e-3, rtol=1e-3)
