@@ -4,6 +4,7 @@
   configs[1]  448x640,  V=2, D=128  -> 112x160x128 volume;  K1 at 56x80
   configs[2]  768x1152, V=4, D=256  -> 192x288x256 volume;  K1 at 96x144 x S256 x V4; K6 on 5 images of 768x1152
   configs[3]  896x1216, V=4, D=256  -> 224x304x256 volume   (fp32 path here; the fp16-feature variant is in test_hip_f16.py)
+  configs[4]  704x1280, V=6, D=512  -> 176x320x512 volume   (the frame one rank of the batch-sharded 8-GPU run processes)
 
 The whole Path-B forward (K6 x 8 -> K3 -> K4 x 11 -> K5) is compared with oracle/pipeline.py end to end — the C/OpenMP
 oracle finishes these sizes in seconds on the GPU box's host cores — and K3 / K1 / K6 are compared block by block.
@@ -24,7 +25,8 @@ pytestmark = pytest.mark.gpu
 ATOL = RTOL = 1e-4
 PATH_A_ATOL = 1e-4  # Path A in inverse-depth space (vendor 2-D convolutions here, oneDNN in the oracle)
 
-CONFIGS = {1: (448, 640, 2, 128), 2: (768, 1152, 4, 256), 3: (896, 1216, 4, 256)}  # H, W, V, D  (BASELINE.json configs[i])
+CONFIGS = {1: (448, 640, 2, 128), 2: (768, 1152, 4, 256), 3: (896, 1216, 4, 256),
+           4: (704, 1280, 6, 512)}  # H, W, V, D  (BASELINE.json configs[i]; [4] = one rank's frame of the 8-GPU config)
 
 
 @pytest.fixture(scope="module")
@@ -55,9 +57,10 @@ def normalise(images):
     return [((im / 255.0 - mean) / std).astype(np.float32)[None] for im in images]
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
 def test_mvsnet_forward_at_baseline_config_vs_oracle_pipeline(cfg, dev):
-    """model.run at the config's full size against the end-to-end CPU oracle: regressed depth rtol 1e-3."""
+    """model.run at the config's full size against the end-to-end CPU oracle: regressed depth rtol 1e-3.
+    cfg 4 = one rank's share of BASELINE configs[4] (704x1280, 6 source views, 512 planes; the 8-GPU run shards frames)."""
     H, W, V, D = CONFIGS[cfg]
     model, sd = seeded_mvsnet(D, 100 + cfg, dev)
     s = gc.synthetic_sample(cfg, H, W, V)
