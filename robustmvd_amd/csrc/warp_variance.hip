@@ -465,29 +465,6 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_kernel(WarpParams p) 
 // LDS (broadcast reads, no VALU) instead of computing and shuffling them, and keep at most three cells in flight
 // (gather_blend_4planes_lds) so that the kernel fits 128 VGPRs = 4 waves per SIMD.  Same arithmetic, operation for
 // operation, as warp_variance_kernel: results are bit-identical.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-// by VALUE on purpose: __builtin_bit_cast applied directly to a vector component (t.y) reads the vector's first dword
-__device__ __forceinline__ f16x2 as_h2(unsigned v) { return __builtin_bit_cast(f16x2, v); }
-__device__ __forceinline__ unsigned as_u32(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
-
-// fp16 taps (4 channels = 8 bytes per lane), fp32 weights and accumulation: fmaf((float)half, w, acc) is one
-// v_fma_mix_f32 (exact f16 -> f32 conversion inside the FMA), so the result equals the fp32 kernel's on the same
-// (fp16-representable) feature values, operation for operation
-__device__ __forceinline__ void accumulate_cell(float4& a1, float4& a2, const float (&w)[4], const u32x2 (&t)[4]) {
-    float4 acc = make_float4(0, 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const f16x2 lo = as_h2(t[k].x), hi = as_h2(t[k].y);
-        acc.x = fmaf((float)lo.x, w[k], acc.x);
-        acc.y = fmaf((float)lo.y, w[k], acc.y);
-        acc.z = fmaf((float)hi.x, w[k], acc.z);
-        acc.w = fmaf((float)hi.y, w[k], acc.w);
-    }
-    a1.x += acc.x; a1.y += acc.y; a1.z += acc.z; a1.w += acc.w;
-    a2.x = fmaf(acc.x, acc.x, a2.x); a2.y = fmaf(acc.y, acc.y, a2.y);
-    a2.z = fmaf(acc.z, acc.z, a2.z); a2.w = fmaf(acc.w, acc.w, a2.w);
-}
 
 template <int MASK, int I, class TAP>
 __device__ __forceinline__ void blend_plane_lds(float4 (&s1)[4], float4 (&s2)[4], const float4 wq, const TAP (&f)[4]) {
@@ -512,17 +489,6 @@ __device__ __forceinline__ void gather_cell_s(u32x4 (&f)[4], __amdgpu_buffer_rsr
     f[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 128u, rowb, 0);
 }
 // fp16 features: 64 bytes per pixel, 8 per lane
-// (the b64 builtins traffic in GCC-style vectors; an implicit conversion to an ext_vector_type silently narrows the load
-// to one dword with this compiler, so the lanes are moved explicitly)
-typedef unsigned int u32x2n __attribute__((vector_size(8)));
-__device__ __forceinline__ u32x2 load_b64(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    const u32x2n r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
-    return u32x2{r[0], r[1]};
-}
-__device__ __forceinline__ void store_b64(u32x2 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
-    const u32x2n r = {v.x, v.y};
-    __builtin_amdgcn_raw_buffer_store_b64(r, rsrc, voff, 0, 0);
-}
 __device__ __forceinline__ void gather_cell_s(u32x2 (&f)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned o, unsigned rowb) {
     f[0] = load_b64(rsrc, o, 0);
     f[1] = load_b64(rsrc, o + 64u, 0);
@@ -1322,8 +1288,22 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
     p.B = B; p.D = D; p.h = h; p.w = w; p.V = V;
     p.layout = layout & 0xff;
     p.exact_grid = (layout & MVD_GRID_EXACT) ? 1 : 0;
-    if (!warp_only && C == 32 && p.layout == MVD_LAYOUT_NDHWC && !p.exact_grid) {
+    if (!warp_only && C == 32 && p.layout == MVD_LAYOUT_NDHWC) {
         int located_minw = 4, ko = 0;
+        bool tile = warp_tile_supported(p, false);
+        int tile_tw = 8, tile_win = 128, tile_nch = 32;
+#ifdef MVD_EXPERIMENTS
+        if (const char* e = exp_env("MVD_K3_CFG")) {
+            tile = false;
+            if (e[0] == 'T') {  // "T<tw>,<win>,<nch>": the LDS-footprint tile kernel (warp_variance_tile.hip)
+                sscanf(e, "T%d,%d,%d", &tile_tw, &tile_win, &tile_nch);
+                return launch_warp_tile(p, st, tile_tw, tile_win, tile_nch, false, p.exact_grid != 0);
+            }
+        }
+#endif
+        // product: LDS-staged footprints, 8x4 key tiles, 8-plane chunks (tools/bench_k3.py)
+        if (tile) return launch_warp_tile(p, st, tile_tw, tile_win, tile_nch, false, p.exact_grid != 0);
+        if (p.exact_grid) return launch_warp<false>(p, C, st);
 #ifdef MVD_EXPERIMENTS
         if (const char* e = exp_env("MVD_K3_CFG")) {
             if (e[0] == 'L') { sscanf(e, "L%d,%d", &located_minw, &ko); if (located_minw == 4 && ko == 0) ko = -1; }  // "L3"/"L4": the located kernel; "L4,<ko>": knock-out
@@ -1392,6 +1372,17 @@ static int run_warp_f16(const void* key_feat, const void* const* src_feat, const
     p.out = (float*)out;
     p.B = B; p.D = D; p.h = h; p.w = w; p.V = V;
     p.layout = MVD_LAYOUT_NDHWC;
+#ifdef MVD_EXPERIMENTS
+    if (const char* e = exp_env("MVD_K3_CFG")) {
+        if (e[0] == 'T') {
+            int tw = 8, win = 128, nch = 8;
+            sscanf(e, "T%d,%d,%d", &tw, &win, &nch);
+            return launch_warp_tile(p, st, tw, win, nch, true, false);
+        }
+        if (e[0] == 'M') return launch_warp_march(p, st, 4, 2, 4, true);
+    }
+#endif
+    if (warp_tile_supported(p, true)) return launch_warp_tile(p, st, 8, 128, 32, true, false);
     return launch_warp_march(p, st, 4, 2, 4, true);
 }
 

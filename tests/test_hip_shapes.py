@@ -341,7 +341,7 @@ def test_full_size_regulariser_and_regression_properties(dev):
     np.testing.assert_allclose(cc[0].cpu().numpy(), ref, atol=2e-4, rtol=1e-3)
 
 
-@pytest.mark.parametrize("cfg", ["lds,4", "lds,8", "wave,4", "wave,8", "4,3", "8,2", "r4,3", "u4,2", "v4,3", "v4,4", "q8,4", "q8,3"])
+@pytest.mark.parametrize("cfg", ["M4,2,4", "L4", "T8,128,8", "T8,96,2", "T16,128,3", "T16,96,8", "T32,128,1", "T32,96,32", "lds,4", "lds,8", "wave,4", "wave,8", "4,3", "8,2", "r4,3", "u4,2", "v4,3", "v4,4", "q8,4", "q8,3"])
 def test_warp_variance_experimental_variants_match_default(cfg, dev, monkeypatch):
     """the experimental forms of K3 (LDS-staged footprints, other plane/occupancy splits; compiled only into
     robustmvd_amd/lib_exp/libmvd_hip_exp.so, never into the product library) give the same volume as the product
