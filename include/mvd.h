@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MVD_VERSION 100 /* 0.1.0 */
-#define MVD_MAX_VIEWS 16
+#define MVD_MAX_VIEWS 32
 
 typedef void* mvd_stream_t; /* hipStream_t */
 

@@ -50,7 +50,7 @@ void orc_warp_variance(const float* key, const float* const* srcs, const float* 
                        const float* depth, int B, int C, int D, int h, int w, int V, int warped_only, float* out) {
     const size_t hw = (size_t)h * w;
     for (int b = 0; b < B; ++b) {
-        float M[16][12];
+        float M[64][12]; /* V <= 64 */
         for (int v = 0; v < V; ++v) {
             const float* P = projs[v] + b * 16;
             const float* Q = key_inv + b * 16;

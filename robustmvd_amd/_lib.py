@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmvd_hip.so")
 # Never loaded by the product path; tools/ and the variants test route calls through it with use_experiments_library().
 EXP_LIB_PATH = os.path.join(_HERE, "lib_exp", "libmvd_hip_exp.so")
 
-MVD_MAX_VIEWS = 16
+MVD_MAX_VIEWS = 32
 LAYOUT_NCDHW = 0
 LAYOUT_NDHWC = 1
 GRID_EXACT = 0x100

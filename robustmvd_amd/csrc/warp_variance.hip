@@ -1053,6 +1053,13 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_march_kernel(WarpPara
     if constexpr (PARK) drain();
 }
 
+// LDS of the marching kernel grows with V (the tile kernel's does not): up to 64 KiB it launches without an attribute and
+// keeps at least two workgroups per CU; beyond that (V >= 13) callers take a kernel whose LDS does not depend on V
+static size_t march_lds_bytes(int V) {
+    return 2 * (size_t)V * 4 * 32 * (sizeof(float4) + sizeof(unsigned)) + 256 * sizeof(float4) + (size_t)V * 3 * sizeof(float4);
+}
+static bool march_fits(int V) { return march_lds_bytes(V) <= 64 * 1024; }
+
 static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int nsets, int nch, bool f16 = false) {
     WarpParams p = p0;
     p.tiles_x = (p.w + 31) / 32;
@@ -1070,8 +1077,7 @@ static int launch_warp_march(const WarpParams& p0, hipStream_t st, int minw, int
         set_error("warp_variance: %lld workgroups exceed the grid limit", nblk);
         return MVD_ERR_INVALID_ARG;
     }
-    const size_t lds = 2 * (size_t)p.V * 4 * 32 * (sizeof(float4) + sizeof(unsigned)) + 256 * sizeof(float4) +
-                       (size_t)p.V * 3 * sizeof(float4);  // 5 KiB per view + key slots + transforms
+    const size_t lds = march_lds_bytes(p.V);  // 5 KiB per view + key slots + transforms (callers check march_fits)
     const dim3 grid((unsigned)nblk);
     timing_begin(st);
 #define MVD_M(MW, NS) hipLaunchKernelGGL((warp_variance_march_kernel<MW, NS>), grid, dim3(256), lds, st, p, nch)
@@ -1291,18 +1297,18 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
     if (!warp_only && C == 32 && p.layout == MVD_LAYOUT_NDHWC) {
         int located_minw = 4, ko = 0;
         bool tile = warp_tile_supported(p, false);
-        int tile_tw = 8, tile_win = 128, tile_nch = 32;
+        int tile_tw = 8, tile_win = 104, tile_nch = 8, tile_sets = 1;
 #ifdef MVD_EXPERIMENTS
         if (const char* e = exp_env("MVD_K3_CFG")) {
             tile = false;
-            if (e[0] == 'T') {  // "T<tw>,<win>,<nch>": the LDS-footprint tile kernel (warp_variance_tile.hip)
-                sscanf(e, "T%d,%d,%d", &tile_tw, &tile_win, &tile_nch);
-                return launch_warp_tile(p, st, tile_tw, tile_win, tile_nch, false, p.exact_grid != 0);
+            if (e[0] == 'T') {  // "T<tw>,<win>,<nch>,<sets>": the LDS-footprint tile kernel (warp_variance_tile.hip)
+                sscanf(e, "T%d,%d,%d,%d", &tile_tw, &tile_win, &tile_nch, &tile_sets);
+                return launch_warp_tile(p, st, tile_tw, tile_win, tile_nch, tile_sets, false, p.exact_grid != 0);
             }
         }
 #endif
         // product: LDS-staged footprints, 8x4 key tiles, 8-plane chunks (tools/bench_k3.py)
-        if (tile) return launch_warp_tile(p, st, tile_tw, tile_win, tile_nch, false, p.exact_grid != 0);
+        if (tile) return launch_warp_tile(p, st, tile_tw, tile_win, tile_nch, tile_sets, false, p.exact_grid != 0);
         if (p.exact_grid) return launch_warp<false>(p, C, st);
 #ifdef MVD_EXPERIMENTS
         if (const char* e = exp_env("MVD_K3_CFG")) {
@@ -1316,7 +1322,8 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
 #endif
         // product: the marching form, 4 chunks per workgroup, two cells in flight, 4 waves per SIMD (tools/bench_k3.py)
         if (ko < 0) return launch_warp_located(p, st, 4, 0);
-        if (located_minw == 4 && ko == 0 && (long long)p.h * p.w * 128 < 0x7fffffffLL) return launch_warp_march(p, st, 4, 2, 4);
+        if (located_minw == 4 && ko == 0 && (long long)p.h * p.w * 128 < 0x7fffffffLL && march_fits(p.V)) return launch_warp_march(p, st, 4, 2, 4);
+        if (located_minw && (size_t)p.V * 4 * 32 * 20 > 64 * 1024) located_minw = 0;  // the located kernel: 2.5 KiB of LDS per view
         if (located_minw) return launch_warp_located(p, st, located_minw, ko);
 #ifdef MVD_EXPERIMENTS
         // MVD_K3_CFG="lds,nd" selects the LDS-staged form (experiments library only)
@@ -1375,14 +1382,18 @@ static int run_warp_f16(const void* key_feat, const void* const* src_feat, const
 #ifdef MVD_EXPERIMENTS
     if (const char* e = exp_env("MVD_K3_CFG")) {
         if (e[0] == 'T') {
-            int tw = 8, win = 128, nch = 8;
-            sscanf(e, "T%d,%d,%d", &tw, &win, &nch);
-            return launch_warp_tile(p, st, tw, win, nch, true, false);
+            int tw = 8, win = 128, nch = 16, sets = 2;
+            sscanf(e, "T%d,%d,%d,%d", &tw, &win, &nch, &sets);
+            return launch_warp_tile(p, st, tw, win, nch, sets, true, false);
         }
         if (e[0] == 'M') return launch_warp_march(p, st, 4, 2, 4, true);
     }
 #endif
-    if (warp_tile_supported(p, true)) return launch_warp_tile(p, st, 8, 128, 32, true, false);
+    if (warp_tile_supported(p, true)) return launch_warp_tile(p, st, 8, 128, 8, 1, true, false);
+    if (!march_fits(V)) {
+        set_error("%s: maps of %dx%d with V=%d: neither the tile kernel (h, w < 65533) nor the marching kernel (V <= 12) applies", who, h, w, V);
+        return MVD_ERR_INVALID_ARG;
+    }
     return launch_warp_march(p, st, 4, 2, 4, true);
 }
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ void store_b64(u32x2 v, __amdgpu_buffer_rsrc_t rsrc, 
 
 // LDS-footprint tile kernel (warp_variance_tile.hip): C = 32, channel-last volume
 bool warp_tile_supported(const WarpParams& p, bool f16);
-int launch_warp_tile(const WarpParams& p0, hipStream_t st, int tw, int win, int nch, bool f16, bool exact);
+int launch_warp_tile(const WarpParams& p0, hipStream_t st, int tw, int win, int nch, int sets, bool f16, bool exact);
 
 #ifdef MVD_EXPERIMENTS
 // experimental launchers (warp_variance_exp.hip); each returns an mvd_status

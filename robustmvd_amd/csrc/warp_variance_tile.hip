@@ -112,7 +112,7 @@ struct ViewRec {          // one per source view
     unsigned pad[2];
 };
 
-template <int TW, int WINPIX, bool F16, bool EXACT, int MINW>
+template <int TW, int WINPIX, bool F16, bool EXACT, int MINW, int SETS>
 __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParams p, int nch) {
     constexpr int P = 8, NPX = 32;
     constexpr unsigned PIXB = F16 ? 64 : 128;  // bytes per pixel of the feature maps and of the volume
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParam
             wq = weights(i);
             unsigned oi = ofs[i];
             asm volatile("" : "+v"(done.a1[0]), "+v"(done.a1[1]), "+v"(done.a2[0]), "+v"(done.a2[1]), "+v"(oi));
-            if (__builtin_amdgcn_ballot_w64(oi != ofs[i - 2]) != 0) {
+            if (__builtin_amdgcn_ballot_w64(oi != ofs[i - SETS]) != 0) {
                 const unsigned o = oi + q_b;
                 if constexpr ((MVD_K3T_KO & 2) != 0) { taps(i, f); }
                 else if constexpr (LDSTAPS) {
@@ -420,21 +420,38 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParam
                 }
             }
         };
-        float4 wA = weights(0), wB = weights(1);
-        TAP fA[4], fB[4];
-        taps(0, fA);
-        taps(1, fB);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SETS == 2) {
+            float4 wA = weights(0), wB = weights(1);
+            TAP fA[4], fB[4];
+            taps(0, fA);
+            taps(1, fB);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < P; i += 2) {
-            accumulate_cell_pk(sm[i], wA, fA);
+            for (int i = 0; i < P; i += 2) {
+                accumulate_cell_pk(sm[i], wA, fA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 2 < P) next(i + 2, wA, fA, sm[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                accumulate_cell_pk(sm[i + 1], wB, fB);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 3 < P) next(i + 3, wB, fB, sm[i + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // One tap set (16 registers fewer: 128 VGPRs, four waves per SIMD, which cover the LDS latency of a refresh instead
+            // of a second set); a plane re-reads its taps only when some lane's cell differs from the previous plane's (host
+            // count: 38 % of the fetches remain)
+            float4 wA = weights(0);
+            TAP fA[4];
+            taps(0, fA);
             __builtin_amdgcn_sched_barrier(0);
-            if (i + 2 < P) next(i + 2, wA, fA, sm[i]);
-            __builtin_amdgcn_sched_barrier(0);
-            accumulate_cell_pk(sm[i + 1], wB, fB);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 3 < P) next(i + 3, wB, fB, sm[i + 1]);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                accumulate_cell_pk(sm[i], wA, fA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < P) next(i + 1, wA, fA, sm[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
@@ -549,11 +566,15 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParam
 #undef MVD_UNIT_BARRIER
 }
 
-template <int TW, int WINPIX, bool F16, bool EXACT, int MINW>
+static size_t tile_lds_bytes(int win, bool f16, int V, int nch) {
+    return 2 * (size_t)win * (f16 ? 64 : 128) + 2 * 4096 + 2 * 1024 + 512 + 128 + (size_t)V * sizeof(ViewRec) + (size_t)nch * 32 +
+           (size_t)nch * V * sizeof(UnitRec);
+}
+
+template <int TW, int WINPIX, bool F16, bool EXACT, int MINW, int SETS>
 static int launch_tile_variant(const WarpParams& p, const dim3& grid, hipStream_t st, int nch) {
-    const size_t lds = 2 * (size_t)WINPIX * (F16 ? 64 : 128) + 2 * 4096 + 2 * 1024 + 512 + 128 + (size_t)p.V * sizeof(ViewRec) +
-                       (size_t)nch * 32 + (size_t)nch * p.V * sizeof(UnitRec);
-    auto* fn = warp_variance_tile_kernel<TW, WINPIX, F16, EXACT, MINW>;
+    const size_t lds = tile_lds_bytes(WINPIX, F16, p.V, nch);
+    auto* fn = warp_variance_tile_kernel<TW, WINPIX, F16, EXACT, MINW, SETS>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return launch_status("warp_variance_tile: hipFuncSetAttribute");
@@ -562,14 +583,14 @@ static int launch_tile_variant(const WarpParams& p, const dim3& grid, hipStream_
     return MVD_OK;
 }
 
-// tile-kernel launcher: tw = tile width (8, 16 or 32; height 32 / tw), win = LDS window pixels (96: four workgroups per
-// CU, 128: three), nch = chunks of 8 planes per workgroup.  Returns MVD_ERR_UNSUPPORTED-style -1 when the shape cannot
-// use this kernel (the caller then takes the gather kernels).
+// tile-kernel launcher: tw = tile width (8, 16 or 32; height 32 / tw), win = LDS window pixels, nch = chunks of 8 planes per
+// workgroup (at most; capped so that the workgroup's LDS keeps the variant's occupancy), sets = tap register sets (2: three
+// waves per SIMD, 1: four).  warp_tile_supported() says whether the shape can use this kernel at all.
 bool warp_tile_supported(const WarpParams& p, bool f16) {
-    return p.h + 3 < 65536 && p.w + 3 < 65536 && (long long)p.h * p.w * (f16 ? 64 : 128) < 0x7fffffffLL;
+    return p.h + 3 < 65536 && p.w + 3 < 65536 && (long long)p.h * p.w * (f16 ? 64 : 128) < 0x7fffffffLL && p.V <= 32;
 }
 
-int launch_warp_tile(const WarpParams& p0, hipStream_t st, int tw, int win, int nch, bool f16, bool exact) {
+int launch_warp_tile(const WarpParams& p0, hipStream_t st, int tw, int win, int nch, int sets, bool f16, bool exact) {
     WarpParams p = p0;
     const int th = 32 / tw;
     p.tiles_x = (p.w + tw - 1) / tw;
@@ -577,9 +598,11 @@ int launch_warp_tile(const WarpParams& p0, hipStream_t st, int tw, int win, int 
     const long long tiles = (long long)p.tiles_x * p.tiles_y;
     p.tiles_per_xcd = (int)((tiles + 7) / 8);
     const int dchunks = (p.D + 7) / 8;
-    // the kernel keeps one mode bit per chunk in a 32-bit mask and 32 bytes of LDS per (chunk, view): at most 4 KiB of those
+    // one mode bit per chunk in a 32-bit mask; 32 bytes of LDS per chunk and per (chunk, view): as many chunks as keep
+    // 4 (one tap set) or 3 (two sets) workgroups per CU
     nch = nch < 1 ? 1 : (nch > 32 ? 32 : nch);
-    if (nch * p.V > 128) nch = 128 / p.V > 0 ? 128 / p.V : 1;
+    const size_t budget = (size_t)160 * 1024 / (sets == 1 ? 4 : 3);
+    while (nch > 1 && tile_lds_bytes(win, f16, p.V, nch) > budget) --nch;
     const int dgroups = (dchunks + nch - 1) / nch;
     const long long nblk = 8LL * p.tiles_per_xcd * dgroups * p.B;
     if (nblk > 0x7fffffffLL) {
@@ -589,21 +612,21 @@ int launch_warp_tile(const WarpParams& p0, hipStream_t st, int tw, int win, int 
     const dim3 grid((unsigned)nblk);
     int rc = MVD_ERR_INVALID_ARG;
     timing_begin(st);
-#define MVD_T(TW_, WIN_, MW_)                                                                                         \
-    if (tw == TW_ && win == WIN_) {                                                                                   \
-        rc = f16 ? (exact ? launch_tile_variant<TW_, WIN_, true, true, MW_>(p, grid, st, nch)                         \
-                          : launch_tile_variant<TW_, WIN_, true, false, MW_>(p, grid, st, nch))                       \
-                 : (exact ? launch_tile_variant<TW_, WIN_, false, true, MW_>(p, grid, st, nch)                        \
-                          : launch_tile_variant<TW_, WIN_, false, false, MW_>(p, grid, st, nch));                     \
+#define MVD_T(TW_, WIN_, MW_, SETS_)                                                                                   \
+    if (tw == TW_ && win == WIN_ && sets == SETS_) {                                                                  \
+        rc = f16 ? (exact ? launch_tile_variant<TW_, WIN_, true, true, MW_, SETS_>(p, grid, st, nch)                  \
+                          : launch_tile_variant<TW_, WIN_, true, false, MW_, SETS_>(p, grid, st, nch))                \
+                 : (exact ? launch_tile_variant<TW_, WIN_, false, true, MW_, SETS_>(p, grid, st, nch)                 \
+                          : launch_tile_variant<TW_, WIN_, false, false, MW_, SETS_>(p, grid, st, nch));              \
     }
-    MVD_T(8, 128, 3)
+    MVD_T(8, 104, 4, 1) MVD_T(8, 128, 4, 1)  // product: fp32 maps, fp16 maps (half the window bytes)
 #ifdef MVD_EXPERIMENTS
-    MVD_T(8, 96, 4) MVD_T(8, 112, 4) MVD_T(16, 128, 3) MVD_T(16, 96, 4) MVD_T(16, 112, 4) MVD_T(32, 128, 3) MVD_T(32, 96, 4)
+    MVD_T(8, 128, 3, 2) MVD_T(8, 96, 4, 1) MVD_T(16, 128, 3, 2) MVD_T(16, 104, 4, 1) MVD_T(16, 96, 4, 1) MVD_T(32, 128, 3, 2) MVD_T(32, 104, 4, 1)
 #endif
 #undef MVD_T
     timing_end(st);
     if (rc == MVD_ERR_INVALID_ARG) {
-        set_error("warp_variance: tile variant tw=%d win=%d is not compiled", tw, win);
+        set_error("warp_variance: tile variant tw=%d win=%d sets=%d is not compiled", tw, win, sets);
         return rc;
     }
     if (rc) return rc;

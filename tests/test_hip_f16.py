@@ -39,7 +39,8 @@ def bordered(f, dev, dtype):
     return out
 
 
-@pytest.mark.parametrize("B,h,w,D,V", [(1, 24, 40, 8, 2), (2, 37, 53, 5, 3), (1, 9, 70, 7, 6), (1, 64, 96, 16, 4)])
+@pytest.mark.parametrize("B,h,w,D,V", [(1, 24, 40, 8, 2), (2, 37, 53, 5, 3), (1, 9, 70, 7, 6), (1, 64, 96, 16, 4),
+                                       (1, 21, 30, 11, 20), (1, 13, 22, 17, 12), (1, 10, 19, 9, 16)])
 def test_warp_variance_f16_equals_f32_kernel_on_fp16_features(B, h, w, D, V, dev):
     from robustmvd_amd import ops
     from test_hip_shapes import mvs_inputs

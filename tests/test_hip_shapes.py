@@ -42,7 +42,10 @@ def mvs_inputs(B, C, h, w, D, V, seed, rot=0.05, trans=0.15, dmin=0.5, dmax=10.0
 
 
 @pytest.mark.parametrize("B,C,h,w,D,V", [(2, 32, 37, 53, 5, 3), (1, 32, 9, 70, 3, 6), (1, 8, 20, 33, 4, 2),
-                                         (1, 64, 11, 17, 3, 1), (1, 32, 64, 96, 9, 4)])
+                                         (1, 64, 11, 17, 3, 1), (1, 32, 64, 96, 9, 4),
+                                         # KITTI's 20 source views (rmvd/data/README.md:322-323), 12 and 16, the API's maximum
+                                         (1, 32, 21, 30, 11, 20), (1, 32, 13, 22, 17, 12), (2, 32, 10, 19, 9, 16), (1, 32, 8, 12, 20, 32),
+                                         (1, 16, 9, 14, 5, 20)])
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_warp_variance_vs_oracle(B, C, h, w, D, V, channels_last, dev):
     from robustmvd_amd import ops
@@ -66,7 +69,8 @@ def test_warp_variance_wide_baseline_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("N,C,h,w,hs,ws,S,V,batched", [(2, 64, 13, 21, 11, 19, 7, 3, True), (1, 128, 5, 40, 5, 40, 9, 1, False),
-                                                       (1, 256, 17, 16, 17, 16, 33, 2, False)])
+                                                       (1, 256, 17, 16, 17, 16, 33, 2, False),
+                                                       (1, 64, 9, 14, 9, 14, 5, 20, False), (2, 64, 6, 9, 7, 8, 4, 32, True)])
 def test_sweep_corr_vs_oracle(N, C, h, w, hs, ws, S, V, batched, dev):
     from robustmvd_amd import ops
     rng = np.random.default_rng(N * 100 + C)
@@ -87,7 +91,7 @@ def test_sweep_corr_vs_oracle(N, C, h, w, hs, ws, S, V, batched, dev):
         np.testing.assert_allclose(corrs[v].cpu().numpy()[~mism], ref_c[v][~mism], atol=ATOL, rtol=RTOL)
 
 
-@pytest.mark.parametrize("V", [2, 3, 5])
+@pytest.mark.parametrize("V", [2, 3, 5, 20, 32])
 def test_fuse_views_vs_oracle(V, dev):
     from robustmvd_amd import ops
     rng = np.random.default_rng(V)
@@ -341,7 +345,7 @@ def test_full_size_regulariser_and_regression_properties(dev):
     np.testing.assert_allclose(cc[0].cpu().numpy(), ref, atol=2e-4, rtol=1e-3)
 
 
-@pytest.mark.parametrize("cfg", ["M4,2,4", "L4", "T8,128,8", "T8,96,2", "T16,128,3", "T16,96,8", "T32,128,1", "T32,96,32", "lds,4", "lds,8", "wave,4", "wave,8", "4,3", "8,2", "r4,3", "u4,2", "v4,3", "v4,4", "q8,4", "q8,3"])
+@pytest.mark.parametrize("cfg", ["M4,2,4", "L4", "T8,128,8,2", "T8,96,2,1", "T16,128,3,2", "T16,104,8,1", "T32,128,1,2", "T32,104,32,1", "T8,104,16,1", "T8,128,16,1", "lds,4", "lds,8", "wave,4", "wave,8", "4,3", "8,2", "r4,3", "u4,2", "v4,3", "v4,4", "q8,4", "q8,3"])
 def test_warp_variance_experimental_variants_match_default(cfg, dev, monkeypatch):
     """the experimental forms of K3 (LDS-staged footprints, other plane/occupancy splits; compiled only into
     robustmvd_amd/lib_exp/libmvd_hip_exp.so, never into the product library) give the same volume as the product
@@ -379,6 +383,50 @@ def test_largest_baseline_shape_runs(dev):
     assert tuple(cost.shape) == (1, D, h, w) and bool(torch.isfinite(cost).all())
     depth_map, conf = ops.softmax_regress(cost, T(depth, dev))
     assert bool(torch.isfinite(depth_map).all()) and float(conf.max()) <= 1.0 + 1e-5
+
+
+def test_mvsnet_20_source_views_vs_oracle_pipeline(dev):
+    """KITTI's evaluation feeds 20 source views (rmvd/data/README.md:322-323): model.run with 21 images against the
+    end-to-end oracle"""
+    import robustmvd_amd as R
+    from oracle import pipeline as PL
+    H, W, D, V = 64, 96, 16, 20
+    model = R.MVSNet(num_sampling_steps=D).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.fill_state_dict(shapes, 32)
+    full = model.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    model = R.add_run_function(model.to(dev))
+    s = gc.synthetic_sample(43, H, W, V)
+    pred, _ = model.run(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0,
+                        depth_range=(np.float32(0.5), np.float32(10.0)))
+    assert pred["depth"].shape == (1, H // 4, W // 4)
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 3, 1, 1)
+    ref = PL.mvsnet_forward([((im[None] / 255.0 - mean) / std).astype(np.float32) for im in s["images"]], [p[None] for p in s["poses"]],
+                            [k[None] for k in s["intrinsics"]], 0, (0.5, 10.0), sd, D)
+    np.testing.assert_allclose(pred["depth"], ref["depth"][0], rtol=1e-3)
+
+
+def test_robustmvd_20_source_views_vs_oracle_pipeline(dev):
+    """Path A with KITTI's 20 source views: sweep (K1) and learned fusion (K2) over 20 views, inverse-depth space"""
+    import robustmvd_amd as R
+    from oracle import pipeline as PL
+    H, W, V = 128, 192, 20
+    model = R.RobustMVD().eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gc.robustmvd_weights(shapes, 6)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = R.add_run_function(model.to(dev))
+    s = gc.synthetic_sample(44, H, W, V)
+    pred, aux = model.run(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0)
+    scale = np.array([[W] * 3, [H] * 3, [1.0] * 3], np.float32)
+    ref = PL.robustmvd_forward([(im / 255.0 - 0.4).astype(np.float32)[None] for im in s["images"]],
+                               [p[None] for p in s["poses"]], [(k / scale)[None] for k in s["intrinsics"]], 0, sd)
+    assert pred["depth"].shape == (1, H // 2, W // 2)
+    np.testing.assert_allclose(aux["invdepth"], ref["invdepth"][0], atol=1e-4, rtol=1e-4)
 
 
 def test_mvsnet_batch2_keyview1_vs_oracle_pipeline(dev):

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--cfgs", nargs="*", default=["product"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--layout", default="ndhwc")
+    ap.add_argument("--exact", action="store_true", help="exact_grid=True: the reference's rounding chain")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     H, W, V, D = CONFIGS[args.config]
@@ -58,13 +59,13 @@ def main():
         os.environ["MVD_K3_CFG"] = "" if alt else cfg
         lib = L.load()
         for _ in range(3):
-            out = ops.warp_variance(feats[0], feats[1:], projs, key_inv, depth, channels_last=cl)
+            out = ops.warp_variance(feats[0], feats[1:], projs, key_inv, depth, channels_last=cl, exact_grid=args.exact)
         ts = []
         for _ in range(args.iters):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); e1.record()
             lib.mvd_arm_kernel_timing(e0.cuda_event, e1.cuda_event)
-            out = ops.warp_variance(feats[0], feats[1:], projs, key_inv, depth, channels_last=cl)
+            out = ops.warp_variance(feats[0], feats[1:], projs, key_inv, depth, channels_last=cl, exact_grid=args.exact)
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
         ms = float(np.median(ts))
