@@ -45,7 +45,8 @@ typedef enum {
 #define MVD_LAYOUT_NDHWC 1 /* (B, D, h, w, C): channel-last, what the engine uses between its own kernels */
 /* OR into `out_layout` of mvd_warp_variance_f32: compute the sampling positions with the reference's own
  * operation chain (IEEE divisions, normalise then un-normalise), rounding for rounding, instead of the default
- * folded form ix = X * rcp(Z) * W/(W-1) - 0.5.  The default is within 1e-4 px of the chain; exact costs ~40 %. */
+ * folded form ix = X * rcp(Z) * W/(W-1) - 0.5.  The default is within 1e-4 px of the chain; exact costs ~5 % (C = 32,
+ * channel-last: only the locate phase of the tile kernel changes). */
 #define MVD_GRID_EXACT 0x100
 /* OR into `out_layout` of mvd_warp_variance_f32: key_feat and every src_feat are not (B,C,h,w) maps but already the
  * zero-bordered channel-last copies (B,h+3,w+3,C) the kernel gathers from (map at rows/cols 1..h / 1..w, zeros around),
@@ -143,6 +144,13 @@ int mvd_warp_variance_f32(const float* key_feat, const float* const* src_feat, c
                           const float* key_proj_inv, const float* depth_values, int B, int C, int D, int h, int w,
                           int V, float* var_out, int out_layout, void* workspace, size_t workspace_bytes,
                           mvd_stream_t stream);
+/* The same, and max |var_out| over the whole volume into *absmax_out (device, one float): what
+ * mvd_conv3d_bn_relu_f32_split scales its activations by.  A by-product of the kernel's store epilogue for C = 32 /
+ * MVD_LAYOUT_NDHWC (no extra pass over the volume), a separate streaming read otherwise. */
+int mvd_warp_variance_absmax_f32(const float* key_feat, const float* const* src_feat, const float* const* src_proj,
+                                 const float* key_proj_inv, const float* depth_values, int B, int C, int D, int h, int w,
+                                 int V, float* var_out, float* absmax_out, int out_layout, void* workspace,
+                                 size_t workspace_bytes, mvd_stream_t stream);
 
 /* K3, fp16-feature variant (BASELINE.json configs[3]: "fp16 features"; SURVEY.md 8b names mvd_warp_variance_{f32,f16}).
  * Same operation as mvd_warp_variance_f32 with MVD_FEAT_NHWC_BORDER | MVD_LAYOUT_NDHWC, C = 32:
@@ -194,14 +202,25 @@ int mvd_pack_conv3d_weights_f16(const float* w, int Cin, int Cout, void* packed,
 int mvd_conv3d_bn_relu_f16in(const void* x, const void* packed_w, const float* scale, const float* shift, float* y, int B,
                              int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
 
-/* K4 first layer, OPT-IN split-operand form (the default conv0 is mvd_conv3d_bn_relu_f32 on fp32 MFMA): fp32 input and
- * fp32 weights, each split exactly into two fp16 terms (a = a_hi + 2^-11 a_lo), products a_hi w_hi + 2^-11 (a_hi w_lo +
- * a_lo w_hi) on v_mfma_f32_16x16x32_f16 with fp32 accumulation; the dropped term is 2^-22 a_lo w_lo, i.e. relative error per
- * product <= ~3 * 2^-22 against fp32's own 2^-24.  x (B,D,h,w,32) fp32 -> y (B,D,h,w,8) fp32; only Cin = 32, Cout = 8. */
+/* K4 first layer, split-operand form (what the model uses by default; mvd_conv3d_bn_relu_f32 on fp32 MFMA is the other
+ * form): fp32 input and fp32 weights, each split exactly into two fp16 terms (a = a_hi + 2^-11 a_lo), products
+ * a_hi w_hi + 2^-11 (a_hi w_lo + a_lo w_hi) on v_mfma_f32_16x16x32_f16 with fp32 accumulation; the dropped term is
+ * 2^-22 a_lo w_lo, i.e. relative error per product <= ~3 * 2^-22 against fp32's own 2^-24, and one accumulator rounding per
+ * 32 products instead of per product: the result is at least as close to the exact convolution as the fp32-MFMA kernel's
+ * (tests/test_hip_f16.py measures both against a float64 oracle).
+ * Range: both operands are scaled by exact powers of two before the split and the result is scaled back, so inputs of any
+ * uniform magnitude (1e-30 .. 1e30, denormals included) keep that accuracy.  The activations' scale comes from
+ * `x_absmax`, a DEVICE pointer to one float holding max |x| over the whole input (mvd_absmax_f32, or the by-product of
+ * mvd_warp_variance_absmax_f32); any upper bound is safe, a tight one most precise: a value v is represented to
+ * |error| <= max(2^-22 |v|, 2^-50 max|x|).  inf / NaN inputs give inf / NaN outputs where they reach, as on fp32.
+ * x (B,D,h,w,32) fp32 -> y (B,D,h,w,8) fp32; only Cin = 32, Cout = 8. */
 size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout);
 int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream);
-int mvd_conv3d_bn_relu_f32_split(const float* x, const void* packed_w, const float* scale, const float* shift, float* y, int B,
-                                 int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
+int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
+                                 float* y, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
+/* max |x[i]| over the FINITE values of n floats (inf and NaN left out, 0 if there is none) into *absmax (device, one
+ * float); a streaming read */
+int mvd_absmax_f32(const float* x, long long n, float* absmax, mvd_stream_t stream);
 
 /* K6 — one layer of MVSNet's FeatureNet (rmvd/models/blocks/mvsnet_components.py:44-66; ConvBnReLU :8-22) as an
  * implicit GEMM on the fp32 matrix cores: Conv2d k x k with padding k/2 (k = 3 stride 1, or k = 5 stride 2), then a
@@ -229,6 +248,10 @@ int mvd_conv2d_bn_relu_f32(const float* x, int in_layout, const float* packed_w,
  * (the reference returns uncertainty = 1 - conf). conf_out may be NULL. */
 int mvd_softmax_regress_f32(const float* cost, const float* depth_values, int B, int D, int h, int w,
                             float* depth_out, float* conf_out, mvd_stream_t stream);
+
+/* Measurement aid (bench.py's `measured_stream_peak_gbs`): fills n floats (n % 4 == 0, dst 16-byte aligned) with a pure
+ * streaming-store pass, the access pattern an HBM-write-bound kernel can reach at best on this device. */
+int mvd_stream_fill_f32(float* dst, long long n, float value, mvd_stream_t stream);
 
 /* Measurement hook (bench.py): arms a pair of hipEvent_t for THIS thread; the next mvd_warp_variance_f32,
  * mvd_homo_warp_f32 or mvd_sweep_corr_f32 call records `start` on its stream immediately before its main kernel

@@ -49,6 +49,9 @@ SIGNATURES = {
     "mvd_warp_variance_workspace_bytes": (_sz, [_i] * 5),
     "mvd_warp_variance_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p] + [_i] * 6
                               + [_c_float_p, _i, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_warp_variance_absmax_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p] + [_i] * 6
+                                     + [_c_float_p, _c_float_p, _i, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_absmax_f32": (_i, [_c_float_p, ctypes.c_longlong, _c_float_p, ctypes.c_void_p]),
     "mvd_warp_variance_f16_workspace_bytes": (_sz, [_i]),
     "mvd_warp_variance_f16": (_i, [ctypes.c_void_p, _pp, _pp, _c_float_p, _c_float_p] + [_i] * 5
                               + [ctypes.c_void_p, ctypes.c_void_p, _sz, ctypes.c_void_p]),
@@ -64,7 +67,7 @@ SIGNATURES = {
                                  + [ctypes.c_void_p]),
     "mvd_conv3d_split_packed_weight_bytes": (_sz, [_i, _i]),
     "mvd_pack_conv3d_weights_split": (_i, [_c_float_p, _i, _i, ctypes.c_void_p, ctypes.c_void_p]),
-    "mvd_conv3d_bn_relu_f32_split": (_i, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7
+    "mvd_conv3d_bn_relu_f32_split": (_i, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7
                                      + [ctypes.c_void_p]),
     "mvd_conv2d_packed_weight_floats": (_sz, [_i, _i, _i]),
     "mvd_pack_conv2d_weights_f32": (_i, [_c_float_p, _i, _i, _i, _c_float_p, ctypes.c_void_p]),
@@ -74,6 +77,7 @@ SIGNATURES = {
     "mvd_bias_leaky_relu_f32": (_i, [_c_float_p, _c_float_p, _i, _i, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]),
     "mvd_dispnet_head_f32": (_i, [_c_float_p, _c_float_p, _c_float_p, _i, ctypes.c_longlong, ctypes.c_void_p]),
     "mvd_arm_kernel_timing": (_i, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mvd_stream_fill_f32": (_i, [_c_float_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]),
     "mvd_warp_variance_backward_workspace_bytes": (_sz, [_i]),
     "mvd_warp_variance_backward_f32": (_i, [_c_float_p, _pp, _pp, _c_float_p, _c_float_p, _c_float_p] + [_i] * 6
                                        + [_c_float_p, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),

@@ -260,10 +260,12 @@ class CostRegNet(nn.Module):
               ("conv5", 32, 64, 2), ("conv6", 64, 64, 1)]
     UPS = [("conv7", 64, 32), ("conv9", 32, 16), ("conv11", 16, 8)]
 
-    def __init__(self, conv0_split=False):
-        """conv0_split (an extension, default off): the first layer's fp32 operands are split into two fp16 terms each and
-        multiplied on fp16 MFMA with fp32 accumulation (ops.conv3d_bn_relu_split: relative error per product ~3 * 2^-22
-        against fp32's 2^-24) instead of running on the fp32 matrix instruction."""
+    def __init__(self, conv0_split=True):
+        """conv0_split (default on): the first layer's fp32 operands are split into two fp16 terms each, after an exact
+        power-of-two range scaling, and multiplied on fp16 MFMA with fp32 accumulation (ops.conv3d_bn_relu_split); its
+        results are at least as close to the exact convolution as the fp32 matrix instruction's (measured against a
+        float64 oracle over magnitudes 1e-30 .. 1e30: tests/test_hip_f16.py).  False: the first layer on fp32 MFMA like
+        the other ten."""
         super().__init__()
         self.conv0_split = bool(conv0_split)
         for name, cin, cout, stride in self.LAYERS:
@@ -301,9 +303,10 @@ class CostRegNet(nn.Module):
         return pk
 
     @ops.inference_only
-    def forward_channels_last(self, x):
+    def forward_channels_last(self, x, x_absmax=None):
         """x (B,D,h,w,32) fp32, or fp16 (the fp16-feature variant: conv0 then runs on fp16 MFMA) -> cost (B,D,h,w) fp32
-        (the single output channel squeezed)."""
+        (the single output channel squeezed).  x_absmax: max |x| as a one-element device tensor when the producer knows it
+        (ops.warp_variance(..., return_absmax=True)); the split first layer otherwise measures it with one more pass."""
         if x.shape[1] % 8 or x.shape[2] % 8 or x.shape[3] % 8:
             raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {tuple(x.shape[1:4])}")
         pk = self._prepare()
@@ -317,7 +320,7 @@ class CostRegNet(nn.Module):
             conv0 = ops.conv3d_bn_relu_f16in(x, pk["conv0_f16"], scale0, shift0, relu=True)
         elif self.conv0_split:
             _, _, _, scale0, shift0, _ = pk["conv0"]
-            conv0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True)
+            conv0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True, x_absmax=x_absmax)
         else:
             conv0 = layer("conv0", x)
         conv2 = layer("conv2", layer("conv1", conv0))

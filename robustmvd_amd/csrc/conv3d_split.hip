@@ -1,4 +1,4 @@
-// K4 first layer with fp32 operands split into two fp16 terms each (OPT-IN; the default conv0 stays on fp32 MFMA).
+// K4 first layer with fp32 operands split into two fp16 terms each, range-safe (the default first layer of the regulariser).
 //
 // conv0 of CostRegNet (rmvd/models/blocks/mvsnet_components.py:78; 32 -> 8, 3x3x3, stride 1, padding 1) is 44 % of the
 // headline step and is capped by the fp32 matrix rate (v_mfma_f32_16x16x4_f32 = the fp32 VALU rate, 1/16 of fp16 MFMA).
@@ -11,6 +11,17 @@
 // [w_hi of the 8 couts | w_lo of the 8 couts]: one MFMA with A = a_hi yields both a_hi w_hi and a_hi w_lo (all 16 columns
 // useful), a second with A = a_lo yields a_lo w_hi (half useful).  2 MFMAs of 16 cycles per (tap, 16 voxels) replace 8
 // fp32 MFMAs of 32 cycles: the layer turns from matrix-bound into an LDS / memory pass.
+//
+// Range: fp16 spans 2^-24 .. 65504, fp32 operands do not.  Both operands are therefore multiplied by exact powers of two
+// before the split and the result by the inverse afterwards (block floating point, nothing is rounded by the scaling):
+//   * activations by 2^-e, e = exponent(max |x| over the whole input) - 14, so that the largest magnitude lands in
+//     [2^14, 2^15).  The caller supplies max |x| in device memory (mvd_absmax_f32, or the by-product of
+//     mvd_warp_variance_absmax_f32 which costs nothing extra); any upper bound is safe, a tight one is most precise.
+//     A value v is then represented to |error| <= max(2^-22 |v|, 2^-50 max|x|): fp32-grade for everything within 2^-26 of the
+//     largest magnitude, and an ABSOLUTE error below fp32's own rounding of the larger terms for what lies underneath.
+//   * each output channel's weights by 2^-k_c, k_c = exponent(max |w_c|) - 10 (computed when the weights are packed).
+// The epilogue multiplies by 2^(e + k_c) before the batch-norm affine.  Inputs of any uniform magnitude (1e-30 .. 1e30,
+// denormals included) give the same relative accuracy; inf / NaN inputs give inf / NaN outputs where they reach, as on fp32.
 //
 // Workgroup (4 waves) = 4 x 32 tile marching through TD + 2 input planes (see the kernel); the fp32 volume is converted to
 // the two fp16 terms while it is staged (global -> registers -> LDS), all 27 weight fragments stay in registers.
@@ -38,14 +49,36 @@ constexpr int S_PLANE_BYTES = 2 * S_HALF_BYTES;
 constexpr int S_ITEMS = S_ROWS * S_COLS * 4;             // (voxel, 8-channel chunk) items per plane
 constexpr int S_NLOAD = (S_ITEMS + 255) / 256;
 
+// per output channel: 2^k_c with k_c = exponent(max |w_c|) - 10 (0 for an all-zero channel), appended to the packed buffer
+__global__ void conv0_split_wscale_kernel(const float* __restrict__ w, float* __restrict__ wscale) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float m = 0.f;
+    for (int e = threadIdx.x; e < 32 * 27; e += 256) {
+        const float v = fabsf(w[(size_t)c * 32 * 27 + e]);
+        m = (v <= 3.4e38f && v > m) ? v : m;  // finite values only
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int ex = (int)((__float_as_uint(red[0]) >> 23) & 0xffu) - 127;
+        const int k = red[0] > 0.f ? max(-100, min(100, ex - 10)) : 0;
+        wscale[c] = ldexpf(1.0f, k);
+    }
+}
+
 // w (8, 32, 3, 3, 3) fp32 -> [tap 27][lane 64][8 halves]: lane l = column l%16 (0..7: w_hi of cout l%16, 8..15: w_lo of cout
-// l%16 - 8), cin 8*(l/16) .. +7
-__global__ void pack_conv0_split_kernel(const float* __restrict__ w, _Float16* __restrict__ packed) {
+// l%16 - 8), cin 8*(l/16) .. +7; weights divided by the channel's 2^k_c first (exact)
+__global__ void pack_conv0_split_kernel(const float* __restrict__ w, const float* __restrict__ wscale, _Float16* __restrict__ packed) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= 27 * 64 * 8) return;
     const int j = e & 7, lane = (e >> 3) & 63, tap = e >> 9;
     const int col = lane & 15, cin = 8 * (lane >> 4) + j, cout = col & 7;
-    const float v = w[((size_t)cout * 32 + cin) * 27 + tap];
+    const float v = w[((size_t)cout * 32 + cin) * 27 + tap] / wscale[cout];
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
     packed[e] = col < 8 ? hi : lo;
@@ -56,6 +89,7 @@ struct SplitParams {
     const char* wpk;
     const float* scale;
     const float* shift;
+    const float* absmax;  // max |x| (device, one float): sets the activations' power-of-two scale
     float* y;             // (B, D, h, w, 8) fp32
     int B, D, h, w, relu;
     int tiles_x, tiles_y, dgroups, td, tiles_per_xcd;
@@ -129,13 +163,23 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     // split two fp32 values into the packed fp16 pairs (hi, lo * 2^11): hi = fp16(a), t = a - hi (exact, mixed-precision fma
     // straight from the packed half), lo = fp16(t * 2^11) written into its half.  5 instructions per pair; the compiler's own
     // sequence for the same arithmetic is 10 (it converts every hi twice and back).
-    float k2048 = 2048.0f;
-    auto split2 = [k2048](float a0, float a1, unsigned& hi, unsigned& lo) {
+    // activation scale 2^-e, e = exponent(max |x|) - 14 clamped to what a normal fp32 power of two can express
+    float k2048 = 2048.0f, xs, xs_inv;
+    {
+        const unsigned mb = __builtin_amdgcn_readfirstlane((int)__float_as_uint(*p.absmax));
+        const int ex = (int)((mb >> 23) & 0xffu) - 127;
+        const int e = max(-125, min(125, ex - 14));
+        xs = __uint_as_float((unsigned)(127 - e) << 23);
+        xs_inv = __uint_as_float((unsigned)(127 + e) << 23);
+    }
+    auto split2 = [k2048, xs](float a0, float a1, unsigned& hi, unsigned& lo) {
         unsigned hp, lp;
         float t0, t1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a0), "v"(a1));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(hp), "v"(a0));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(hp), "v"(a1));
+        // hi = fp16(a * 2^-e) (one rounding: the scaling is exact), t = a * 2^-e - hi (exact), lo = fp16(t * 2^11)
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(hp) : "v"(a0), "s"(xs));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(hp) : "v"(a1), "s"(xs));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(t0) : "v"(a0), "s"(xs), "v"(hp));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(t1) : "v"(a1), "s"(xs), "v"(hp));
         asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(lp) : "v"(t0), "s"(k2048));
         asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lp) : "v"(t1), "s"(k2048));
         hi = hp;
@@ -162,6 +206,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     // epilogue constants of the lanes that end up with a result: column (cout) l%16 < 8
     const int col = lane & 15;
     float esc_ = p.scale[col & 7], esh_ = p.shift[col & 7];
+    float eun_ = reinterpret_cast<const float*>(p.wpk + 27 * 64 * 16)[col & 7] * xs_inv;  // 2^(k_c + e): undoes both scalings
     const float floor_ = p.relu ? 0.f : -__builtin_inff();
     const int xh = wv & 1, rp = wv >> 1;
 
@@ -190,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     const size_t yplane_f = (size_t)h * w * 8;
 
     fetch(dz0 - 1);
-    asm volatile("" : "+v"(esc_), "+v"(esh_));  // the per-lane epilogue constants have landed: no vmcnt wait inside the loop
+    asm volatile("" : "+v"(esc_), "+v"(esh_), "+v"(eun_));  // the per-lane epilogue constants have landed: no vmcnt wait inside the loop
     stash(dz0 - 1);
     fetch(dz0);
 
@@ -269,7 +314,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
                 const float cur = hl;
                 if (g + 1 < 8) hl = __shfl_down(acc[0][(g + 1) >> 2][0][(g + 1) & 3], 8, 16);
                 float r = __builtin_fmaf(cur + acc[0][row][1][i], 1.0f / 2048.0f, acc[0][row][0][i]);
-                r = fmaxf(__builtin_fmaf(r, esc_, esh_), floor_);
+                r = fmaxf(__builtin_fmaf(r * eun_, esc_, esh_), floor_);
                 if (!(SPLIT_KO & 2) || r == 12345.678f)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs_out, ox + i < w ? yoff[row] + 32u * i : OOB, 0, 0);
             } else if (!(SPLIT_KO & 4)) {  // staging of plane z+1 / reload with plane z+2: item k, float pair q of its 4
@@ -306,24 +351,26 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 
 extern "C" {
 
-size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout) { return (Cin == 32 && Cout == 8) ? (size_t)27 * 64 * 16 : 0; }
+size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout) { return (Cin == 32 && Cout == 8) ? (size_t)27 * 64 * 16 + 8 * sizeof(float) : 0; }
 
 int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream) {
     MVD_REQUIRE(w && packed, "pack_conv3d_weights_split: NULL argument");
     MVD_REQUIRE(Cin == 32 && Cout == 8, "pack_conv3d_weights_split: only the 32 -> 8 first layer of CostRegNet is built (got %d -> %d)", Cin, Cout);
-    hipLaunchKernelGGL(mvd::pack_conv0_split_kernel, dim3((27 * 64 * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+    float* wscale = reinterpret_cast<float*>(static_cast<char*>(packed) + (size_t)27 * 64 * 16);
+    hipLaunchKernelGGL(mvd::conv0_split_wscale_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, w, wscale);
+    hipLaunchKernelGGL(mvd::pack_conv0_split_kernel, dim3((27 * 64 * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wscale,
                        (_Float16*)packed);
     return mvd::launch_status("pack_conv3d_weights_split");
 }
 
-int mvd_conv3d_bn_relu_f32_split(const float* x, const void* packed_w, const float* scale, const float* shift, float* y, int B,
-                                 int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream) {
-    MVD_REQUIRE(x && packed_w && scale && shift && y, "conv3d_split: NULL argument");
+int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
+                                 float* y, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream) {
+    MVD_REQUIRE(x && x_absmax && packed_w && scale && shift && y, "conv3d_split: NULL argument");
     MVD_REQUIRE(Cin == 32 && Cout == 8, "conv3d_split: only the 32 -> 8 first layer of CostRegNet is built (got %d -> %d)", Cin, Cout);
     MVD_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "conv3d_split: non-positive dimension");
     MVD_REQUIRE((long long)h * w * 128 < 0x7fffffffLL, "conv3d_split: one input plane exceeds the 31-bit byte-offset range");
     mvd::SplitParams p{};
-    p.x = x; p.wpk = (const char*)packed_w; p.scale = scale; p.shift = shift; p.y = y;
+    p.x = x; p.absmax = x_absmax; p.wpk = (const char*)packed_w; p.scale = scale; p.shift = shift; p.y = y;
     p.B = B; p.D = D; p.h = h; p.w = w; p.relu = relu;
     p.tiles_x = (w + mvd::S_TW - 1) / mvd::S_TW;
     p.tiles_y = (h + mvd::S_TH - 1) / mvd::S_TH;

@@ -113,7 +113,27 @@ __global__ void __launch_bounds__(256) dispnet_head_kernel(const float* __restri
 }
 }  // namespace mvd
 
+namespace mvd {
+// measurement aid (bench.py): a pure streaming-store pass, 16 bytes per lane, 16 KiB contiguous per workgroup and step
+__global__ void __launch_bounds__(256) stream_fill_kernel(float4* __restrict__ out, long long n4, float seed) {
+    const float v = seed + threadIdx.x;
+    const float4 r = make_float4(v, v + 1, v + 2, v + 3);
+    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (long long)gridDim.x * 1024) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * 256 < n4) out[i + k * 256] = r;
+    }
+}
+}  // namespace mvd
+
 extern "C" {
+int mvd_stream_fill_f32(float* dst, long long n, float value, mvd_stream_t stream) {
+    MVD_REQUIRE(dst && n > 0 && n % 4 == 0 && ((size_t)dst % 16) == 0, "stream_fill: NULL / misaligned destination or count not a multiple of 4");
+    const long long n4 = n / 4, want = (n4 + 1023) / 1024;
+    hipLaunchKernelGGL(mvd::stream_fill_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(dst), n4, value);
+    return mvd::launch_status("stream_fill");
+}
 int mvd_dispnet_head_f32(const float* x, float* pred, float* ent, int N, long long HW, mvd_stream_t stream) {
     MVD_REQUIRE(x && pred && ent && N > 0 && N <= 65535 && HW > 0, "dispnet_head: bad argument");
     const unsigned gx = (unsigned)((HW + 255) / 256 > 1024 ? 1024 : (HW + 255) / 256);

@@ -1237,10 +1237,38 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
     return launch_status("warp_variance");
 }
 
+// max |x| over the FINITE values of n floats into *absmax (zeroed first): NaN and inf do not take part, so that one bad voxel
+// does not set the scale of everything else.  A streaming read: 16 bytes per lane, grid-stride.
+__device__ __forceinline__ float finite_abs_or_zero(float v) {
+    const float a = fabsf(v);
+    return a <= 3.402823466e38f ? a : 0.f;  // false for inf and NaN
+}
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    const long long n4 = n / 4, stride = (long long)gridDim.x * 256;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(finite_abs_or_zero(v.x), finite_abs_or_zero(v.y))), fmaxf(finite_abs_or_zero(v.z), finite_abs_or_zero(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) m = fmaxf(m, finite_abs_or_zero(x[n4 * 4 + threadIdx.x]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+int absmax_launch(const float* x, long long n, float* absmax, hipStream_t st) {
+    if (hipMemsetAsync(absmax, 0, sizeof(float), st) != hipSuccess) return launch_status("absmax: memset");
+    if (n <= 0) return MVD_OK;
+    const long long want = (n / 4 + 255) / 256;
+    const unsigned nblk = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+    hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(absmax));
+    return launch_status("absmax");
+}
+
 // shared by the two entry points: validates, lays out the workspace, repacks, composes, launches
 static int run_warp(const float* key_feat, const float* const* src_feat, const float* const* src_proj,
                     const float* key_proj_inv, const float* depth_values, int B, int C, int D, int h, int w, int V,
-                    float* out, int layout, void* workspace, size_t workspace_bytes, hipStream_t st, bool warp_only) {
+                    float* out, int layout, void* workspace, size_t workspace_bytes, hipStream_t st, bool warp_only,
+                    float* absmax = nullptr, bool* absmax_done = nullptr) {
     const char* who = warp_only ? "homo_warp" : "warp_variance";
     MVD_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "%s: non-positive dimension (h, w must be >= 2)", who);
     MVD_REQUIRE(V >= 1 && V <= MVD_MAX_VIEWS, "%s: V=%d outside 1..%d", who, V, MVD_MAX_VIEWS);
@@ -1308,7 +1336,14 @@ static int run_warp(const float* key_feat, const float* const* src_feat, const f
         }
 #endif
         // product: LDS-staged footprints, 8x4 key tiles, 8-plane chunks (tools/bench_k3.py)
-        if (tile) return launch_warp_tile(p, st, tile_tw, tile_win, tile_nch, tile_sets, false, p.exact_grid != 0);
+        if (tile) {
+            if (absmax) {
+                if (hipMemsetAsync(absmax, 0, sizeof(float), st) != hipSuccess) return launch_status("warp_variance: memset");
+                p.absmax = absmax;
+                *absmax_done = true;  // a by-product of the tile kernel; after any other kernel the caller runs a separate pass
+            }
+            return launch_warp_tile(p, st, tile_tw, tile_win, tile_nch, tile_sets, false, p.exact_grid != 0);
+        }
         if (p.exact_grid) return launch_warp<false>(p, C, st);
 #ifdef MVD_EXPERIMENTS
         if (const char* e = exp_env("MVD_K3_CFG")) {
@@ -1460,6 +1495,25 @@ int mvd_warp_variance_f32(const float* key_feat, const float* const* src_feat, c
     MVD_REQUIRE((out_layout & 0xff) == MVD_LAYOUT_NCDHW || (out_layout & 0xff) == MVD_LAYOUT_NDHWC, "warp_variance: bad layout");
     return mvd::run_warp(key_feat, src_feat, src_proj, key_proj_inv, depth_values, B, C, D, h, w, V, var_out, out_layout,
                          workspace, workspace_bytes, (hipStream_t)stream, false);
+}
+
+int mvd_warp_variance_absmax_f32(const float* key_feat, const float* const* src_feat, const float* const* src_proj,
+                                 const float* key_proj_inv, const float* depth_values, int B, int C, int D, int h, int w,
+                                 int V, float* var_out, float* absmax_out, int out_layout, void* workspace, size_t workspace_bytes,
+                                 mvd_stream_t stream) {
+    MVD_REQUIRE(key_feat && src_feat && src_proj && key_proj_inv && depth_values && var_out && absmax_out,
+                "warp_variance_absmax: NULL argument");
+    MVD_REQUIRE((out_layout & 0xff) == MVD_LAYOUT_NCDHW || (out_layout & 0xff) == MVD_LAYOUT_NDHWC, "warp_variance: bad layout");
+    bool done = false;
+    int rc = mvd::run_warp(key_feat, src_feat, src_proj, key_proj_inv, depth_values, B, C, D, h, w, V, var_out, out_layout,
+                           workspace, workspace_bytes, (hipStream_t)stream, false, absmax_out, &done);
+    if (rc == MVD_OK && !done) rc = mvd::absmax_launch(var_out, (long long)B * C * D * h * w, absmax_out, (hipStream_t)stream);
+    return rc;
+}
+
+int mvd_absmax_f32(const float* x, long long n, float* absmax, mvd_stream_t stream) {
+    MVD_REQUIRE(x && absmax && n >= 0, "absmax: NULL argument or negative count");
+    return mvd::absmax_launch(x, n, absmax, (hipStream_t)stream);
 }
 
 int mvd_homo_warp_f32(const float* src_feat, const float* src_proj, const float* key_proj_inv,

@@ -17,6 +17,7 @@ struct WarpParams {
     int layout;             // MVD_LAYOUT_*
     int tiles_x, tiles_y, tiles_per_xcd;  // filled by the launchers
     int exact_grid;  // 1: sampling positions follow the reference's operation chain rounding for rounding
+    float* absmax;   // optional (device, one float, zeroed by the launcher): receives max |out| (tile kernel; fp32 volume)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

@@ -463,6 +463,8 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParam
 
     // ---- S: variance of chunk c, always 8 stores per lane: planes past D, or every plane when `drop` (a failed chunk of
     // pass 0), go through an empty descriptor (dropped, but counted by vmcnt) ----
+    float amax = 0.f;  // max |variance| this lane has stored (by-product for the next layer's range scaling), if asked for
+    const bool want_absmax = p.absmax != nullptr;
     auto store_chunk = [&](const Sums (&sm)[P], int c, bool drop) {
         int bx, by;
         const int t = opaque_tid();
@@ -479,6 +481,11 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParam
             const unsigned long long pb = plane0 + (i < nvalid ? (unsigned long long)i * plane_bytes : 0ull);
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(pb), 0, i < nvalid ? (int)plane_bytes : 0, 0x00020000);
             if constexpr ((MVD_K3T_KO & 4) != 0) { if (r.x != 123.456f) continue; }
+            if (want_absmax && i < nvalid) {  // wave-uniform.  Finite values only: a quad with an inf or NaN is left out
+                const float qm = fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w)));  // v_max_f32 drops NaNs
+                const bool fin = fabsf(r.x) + fabsf(r.y) + fabsf(r.z) + fabsf(r.w) <= 3.402823466e38f;   // false if any is inf / NaN
+                amax = fin ? fmaxf(amax, qm) : amax;
+            }
             if constexpr (F16) {  // round to nearest even, one rounding
                 const f16x2 lo = {(_Float16)r.x, (_Float16)r.y}, hi = {(_Float16)r.z, (_Float16)r.w};
                 store_b64(u32x2{as_u32(lo), as_u32(hi)}, orsrc, out_off);
@@ -564,6 +571,13 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParam
         }
     }
 #undef MVD_UNIT_BARRIER
+    if (want_absmax) {  // non-negative floats order like their bit patterns
+        unsigned m = __float_as_uint(amax);
+        m = max(m, row_shr<1>(m)); m = max(m, row_shr<2>(m)); m = max(m, row_shr<4>(m)); m = max(m, row_shr<8>(m));
+        m = max(m, (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x142, 0xa, 0xf, false));
+        m = max(m, (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x143, 0xc, 0xf, false));
+        if ((tid & 63) == 63) atomicMax(reinterpret_cast<unsigned*>(p.absmax), m);
+    }
 }
 
 static size_t tile_lds_bytes(int win, bool f16, int V, int nch) {

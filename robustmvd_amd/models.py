@@ -146,7 +146,8 @@ class RobustMVD(nn.Module):
 
 
 class MVSNet(nn.Module):
-    def __init__(self, sample_in_inv_depth_space=False, num_sampling_steps=192, half_features=False, conv0_split=False):
+    def __init__(self, sample_in_inv_depth_space=False, num_sampling_steps=192, half_features=False, conv0_split=True,
+                 exact_grid=False):
         """half_features (an extension; the reference has no such switch): BASELINE.json configs[3] — the feature maps
         are rounded to fp16 before the sweep, the variance volume is stored fp16 and the regulariser's first layer runs
         on fp16 MFMA with fp32 accumulation; everything else (positions, blend, variance, layers 2..11, soft argmin)
@@ -157,7 +158,8 @@ class MVSNet(nn.Module):
             raise NotImplementedError("sample_in_inv_depth_space=True is a dead branch in the reference "
                                       "(tensor[::-1] raises, mvsnet.py:50,56-63)")
         self.feature = FeatureNet()
-        self.cost_regularization = CostRegNet(conv0_split=conv0_split)  # opt-in split-operand first layer, see CostRegNet
+        self.cost_regularization = CostRegNet(conv0_split=conv0_split)  # split-operand first layer, see CostRegNet
+        self.exact_grid = bool(exact_grid)  # K3's sampling positions by the reference's own rounding chain (blocks/utils.py:234-266)
         self.num_sampling_steps = num_sampling_steps
         self.sample_in_inv_depth_space = False
         self._intrinsics_scale_host = torch.tensor([[0.25] * 3, [0.25] * 3, [1.0] * 3])  # feature maps are 1/4 resolution
@@ -224,11 +226,16 @@ class MVSNet(nn.Module):
         if self.half_features:
             feats = ops.to_f16(feats)  # one rounding to fp16 (zero border stays zero)
         feats = list(torch.split(feats, n, 0))
+        amax = None
         if self.half_features:
             var = ops.warp_variance_f16(feats[0], feats[1:], projs[1:], projs[0], depth_samples)                          # K3 (fp16)
+        elif self.cost_regularization.conv0_split:  # the split first layer scales its activations by max |var|: a by-product of K3
+            var, amax = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True, staged=True,
+                                          exact_grid=self.exact_grid, return_absmax=True)                        # K3
         else:
-            var = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True, staged=True)  # K3
-        cost = self.cost_regularization.forward_channels_last(var)                                              # K4
+            var = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True, staged=True,
+                                    exact_grid=self.exact_grid)                                                  # K3
+        cost = self.cost_regularization.forward_channels_last(var, x_absmax=amax)                               # K4
         del var
         depth, conf = ops.softmax_regress(cost, depth_samples)                                                  # K5
         pred = {"depth": depth.unsqueeze(1), "depth_uncertainty": (1 - conf).unsqueeze(1)}

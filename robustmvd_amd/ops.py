@@ -157,9 +157,11 @@ def fuse_views(corrs, masks, scores):
 
 @inference_only
 def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, channels_last=False, exact_grid=False,
-                  staged=False):
+                  staged=False, return_absmax=False):
     """K3. key_feat (B,C,h,w); src_feats V x (B,C,h,w); src_projs V x (B,4,4); key_proj_inv (B,4,4);
     depth_values (B,D).  Returns the variance volume (B,C,D,h,w), or (B,D,h,w,C) if channels_last.
+    return_absmax: also returns max |volume| as a one-element device tensor (mvd_warp_variance_absmax_f32: a by-product of
+    the store epilogue for C = 32 channel-last), which conv3d_bn_relu_split takes as its activation range.
     exact_grid: sampling positions follow the reference's operation chain rounding for rounding (MVD_GRID_EXACT).
     staged: the feature maps are the zero-bordered channel-last (B,h+3,w+3,C) copies K6 writes
     (conv2d_bn_relu(..., out_layout=LAYOUT_NHWC_BORDER)); the re-packing launches are skipped (MVD_FEAT_NHWC_BORDER)."""
@@ -190,10 +192,29 @@ def warp_variance(key_feat, src_feats, src_projs, key_proj_inv, depth_values, ch
     a_p, k2 = L.ptr_array(projs)
     flags = (L.LAYOUT_NDHWC if channels_last else L.LAYOUT_NCDHW) | (L.GRID_EXACT if exact_grid else 0) | \
         (L.FEAT_NHWC_BORDER if staged else 0)
+    if return_absmax:
+        amax = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.mvd_warp_variance_absmax_f32(L.ptr(kf), a_s, a_p, L.ptr(kpi), L.ptr(dv), B, C, D, h, w, V, L.ptr(out),
+                                                  L.ptr(amax), flags, L.ptr(wsp), wsb, L.stream_of(kf))
+        L.check(rc, "mvd_warp_variance_absmax_f32")
+        return out, amax
     with torch.cuda.device(dev):
         rc = lib.mvd_warp_variance_f32(L.ptr(kf), a_s, a_p, L.ptr(kpi), L.ptr(dv), B, C, D, h, w, V, L.ptr(out), flags,
                                        L.ptr(wsp), wsb, L.stream_of(kf))
     L.check(rc, "mvd_warp_variance_f32")
+    return out
+
+
+@inference_only
+def absmax(x):
+    """max |x| over a float32 device tensor as a one-element device tensor (NaNs ignored; mvd_absmax_f32, a streaming read)."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mvd_absmax_f32(L.ptr(x), x.numel(), L.ptr(out), L.stream_of(x))
+    L.check(rc, "mvd_absmax_f32")
     return out
 
 
@@ -366,9 +387,11 @@ def pack_conv3d_weights_split(weight):
 
 
 @inference_only
-def conv3d_bn_relu_split(x, packed, scale, shift, relu=True):
-    """K4 first layer, opt-in split-operand form: x (B,D,h,w,32) fp32 -> (B,D,h,w,8) fp32 on fp16 MFMA with two-term
-    operand splitting (relative error per product ~3 * 2^-22; mvd_conv3d_bn_relu_f32_split)."""
+def conv3d_bn_relu_split(x, packed, scale, shift, relu=True, x_absmax=None):
+    """K4 first layer, split-operand form: x (B,D,h,w,32) fp32 -> (B,D,h,w,8) fp32 on fp16 MFMA with two-term operand
+    splitting and power-of-two range scaling (mvd_conv3d_bn_relu_f32_split; fp32-grade results for inputs of any
+    magnitude).  x_absmax: one-element device tensor with max |x| (warp_variance(..., return_absmax=True)); computed here
+    with a streaming pass over x when omitted."""
     lib = L.load()
     x = L.as_f32(x, "x")
     if x.dim() != 5 or x.shape[-1] != 32:
@@ -378,9 +401,12 @@ def conv3d_bn_relu_split(x, packed, scale, shift, relu=True):
     scale = L.as_f32(scale, "scale", (8,), dev)
     shift = L.as_f32(shift, "shift", (8,), dev)
     y = torch.empty((B, D, h, w, 8), dtype=torch.float32, device=dev)
+    if x_absmax is None:
+        x_absmax = absmax(x)
+    x_absmax = L.as_f32(x_absmax, "x_absmax", (1,), dev)
     with torch.cuda.device(dev):
-        rc = lib.mvd_conv3d_bn_relu_f32_split(L.ptr(x), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), B, D, h, w, 32, 8,
-                                              int(bool(relu)), L.stream_of(x))
+        rc = lib.mvd_conv3d_bn_relu_f32_split(L.ptr(x), L.ptr(x_absmax), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), B, D, h, w,
+                                              32, 8, int(bool(relu)), L.stream_of(x))
     L.check(rc, "mvd_conv3d_bn_relu_f32_split")
     return y
 

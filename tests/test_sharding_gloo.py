@@ -78,3 +78,57 @@ def test_two_rank_frame_sharding():
     assert sorted(seen) == list(range(nframes))
     for i in range(nframes):
         np.testing.assert_array_equal(seen[i], _frame_result(i))
+
+
+def _bench_worker(rank, world, port, q, fail_rank):
+    """runs bench.py's own main() on a gloo rank with the model stubbed (MVD_BENCH_STUB=1)"""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world), "MVD_BENCH_STUB": "1", "MVD_BENCH_SETTLE": "1"})
+    if fail_rank is not None:
+        os.environ["MVD_BENCH_FAIL_H2D_RANK"] = str(fail_rank)
+    sys.path.insert(0, ROOT)
+    import io
+    import contextlib
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1"])
+    q.put((rank, out, buf.getvalue()))
+
+
+def _run_bench(world, fail_rank=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+def test_bench_main_control_flow_on_two_gloo_ranks():
+    """bench.py's main(): rank environment, round-robin frames, barrier-bracketed timed region with the max-over-ranks time,
+    ONE JSON line from rank 0 with the whole-job value, and the h2d_inclusive block at world 2 — the model call stubbed."""
+    import json
+    (r0, out0, text0), (r1, out1, text1) = _run_bench(2)
+    assert text1.strip() == ""                       # only rank 0 prints
+    lines = [l for l in text0.splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["frames_of_rank0"] == [0, 2] and out1["frames_of_rank0"] == [1, 3]   # frame = rank + world * i
+    # both ranks hold the same max-over-ranks time: value = world * steps / time
+    assert abs(out0["ms_per_step"] - out1["ms_per_step"]) < 1e-9
+    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    assert "value" in line["h2d_inclusive"] and "stub" in line
+
+
+def test_bench_h2d_block_survives_a_lone_failing_rank():
+    """one rank fails while setting up h2d_inclusive: both skip the block (all-reduced ok flag), nobody hangs, the headline stays"""
+    (r0, out0, _), (r1, out1, _) = _run_bench(2, fail_rank=1)
+    assert "skipped" in out0["h2d_inclusive"] and "skipped" in out1["h2d_inclusive"]
+    assert out0["value"] > 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""conv0 at a BASELINE config: default fp32-MFMA kernel vs the opt-in split-operand (2 x fp16 terms) kernel: time and
-difference.  GPU box only."""
+"""conv0 at a BASELINE config: fp32-MFMA kernel vs the split-operand (2 x fp16 terms, range-scaled) kernel: time and
+difference; the standalone max |x| pass timed beside it (inside the model it is a by-product of K3).  GPU box only."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,8 +32,10 @@ def timeit(fn, n=10):
 
 
 t0, y0 = timeit(lambda: ops.conv3d_bn_relu(x, w32, 32, 8, sc, sh, L.CONV3D_STRIDE1, relu=True))
-t1, y1 = timeit(lambda: ops.conv3d_bn_relu_split(x, wsp, sc, sh, relu=True))
+amax = ops.absmax(x)
+t1, y1 = timeit(lambda: ops.conv3d_bn_relu_split(x, wsp, sc, sh, relu=True, x_absmax=amax))
+t2, _ = timeit(lambda: ops.absmax(x))
 ref = torch.nn.functional.conv3d(x[0].permute(3, 0, 1, 2)[None, :, :32].double(), wt.double(), padding=1)[0, :, :32] if False else None
 d = (y1 - y0).abs()
-print(f"conv0 {D}x{h}x{w}: fp32 MFMA {t0:.3f} ms, split fp16x2 {t1:.3f} ms ({t0 / t1:.2f}x); max |diff| {float(d.max()):.3e} "
+print(f"conv0 {D}x{h}x{w}: fp32 MFMA {t0:.3f} ms, split fp16x2 {t1:.3f} ms ({t0 / t1:.2f}x), absmax pass {t2:.3f} ms; max |diff| {float(d.max()):.3e} "
       f"(output max {float(y0.abs().max()):.3f}), mean |diff| {float(d.mean()):.3e}")
