@@ -46,9 +46,9 @@ SETTLE_FORWARDS = int(os.environ.get("MVD_BENCH_SETTLE", "12"))
 HALF_FEATURES = {3}
 
 
-def build_mvsnet(D, dev, seed=0, half_features=False, conv0_split=True):
+def build_mvsnet(D, dev, seed=0, half_features=False, conv0_split=True, exact_grid=False):
     import robustmvd_amd as R
-    model = R.MVSNet(num_sampling_steps=D, half_features=half_features, conv0_split=conv0_split).eval()
+    model = R.MVSNet(num_sampling_steps=D, half_features=half_features, conv0_split=conv0_split, exact_grid=exact_grid).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = gc.fill_state_dict(shapes, seed)
     full = model.state_dict()
@@ -410,6 +410,26 @@ def main(argv=None):
 
     if extras and not half:
         guarded("conv0_fp32_mfma", fp32_conv0_block)
+
+    def exact_grid_block():
+        """Extra, not the headline: MVSNet(exact_grid=True) — K3's sampling positions by the reference's own rounding chain
+        (IEEE divisions, normalise then un-normalise: blocks/utils.py:234-266) instead of the folded form; with it every pixel
+        of the full-size forward is within rtol 1e-3 of the oracle (tests/test_hip_configs.py).  Reports the step and K3's time."""
+        mx, _ = build_mvsnet(D, dev, half_features=half, exact_grid=True)
+        evx = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in evx:
+            a.record(); b.record()
+        torch.cuda.synchronize(dev)
+        dtx = timed_loop(mx, samples, args.steps, args.warmup, world, dev,
+                         lambda i: lib.mvd_arm_kernel_timing(evx[i][0].cuda_event, evx[i][1].cuda_event), cdev)
+        k3x = float(np.mean([a.elapsed_time(b) for a, b in evx]))
+        out["exact_grid"] = {"value": world * args.steps / dtx, "unit": "depth-maps/sec", "ms_per_step": dtx / args.steps * 1e3,
+                             "warp_variance_ms": k3x, "warp_variance_ms_headline": k3_ms,
+                             "note": "MVSNet(exact_grid=True): reference rounding chain in K3's locate phase; not the headline value"}
+        del mx
+
+    if extras and not half:
+        guarded("exact_grid", exact_grid_block)
 
     def mfma_roofline_block():
         """Second roofline block: the LONGEST kernel of the step, the regulariser's first layer (K4 conv0: 3x3x3, 32 -> 8) in its

@@ -39,9 +39,9 @@ def T(x, dev):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
 
-def seeded_mvsnet(D, seed, dev):
+def seeded_mvsnet(D, seed, dev, **kw):
     import robustmvd_amd as R
-    model = R.MVSNet(num_sampling_steps=D).eval()
+    model = R.MVSNet(num_sampling_steps=D, **kw).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = gc.fill_state_dict(shapes, seed)
     full = model.state_dict()
@@ -77,6 +77,37 @@ def test_mvsnet_forward_at_baseline_config_vs_oracle_pipeline(cfg, dev):
     np.testing.assert_allclose(got, want, rtol=1e-2)
     unc = np.abs(pred["depth_uncertainty"] - ref["depth_uncertainty"][0])
     assert (unc < 2e-3).mean() > 0.999  # 4-bin confidence: trunc(E[idx]) can flip a bin at a few pixels
+
+
+def test_mvsnet_exact_grid_at_headline_config_every_pixel(dev):
+    """MVSNet(exact_grid=True) — K3's sampling positions by the reference's own rounding chain
+    (blocks/utils.py:234-266, IEEE divisions) inside the tile kernel — at configs[2] full size: EVERY pixel of the regressed
+    depth within rtol 1e-3 of oracle/pipeline.py (SURVEY 8c as written, no outlier allowance)."""
+    H, W, V, D = CONFIGS[2]
+    model, sd = seeded_mvsnet(D, 102, dev, exact_grid=True)
+    s = gc.synthetic_sample(2, H, W, V)
+    pred, _ = model.run(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0,
+                        depth_range=(np.float32(0.5), np.float32(10.0)))
+    ref = PL.mvsnet_forward(normalise(s["images"]), [p[None] for p in s["poses"]], [k[None] for k in s["intrinsics"]],
+                            0, (0.5, 10.0), sd, D)
+    rel = np.abs(pred["depth"] - ref["depth"][0]) / np.abs(ref["depth"][0])
+    print(f"exact grid, configs[2]: max rel depth error {rel.max():.2e}, 99.99th percentile {np.quantile(rel, 0.9999):.2e}")
+    np.testing.assert_allclose(pred["depth"], ref["depth"][0], rtol=1e-3)
+
+
+def test_warp_variance_exact_grid_block_tolerance_no_allowance(dev):
+    """K3 with exact_grid=True on a 64-plane slab of the headline volume (192x288, V=4): every element within the block
+    tolerance atol = rtol = 1e-4 of the C oracle, no outlier fraction"""
+    from robustmvd_amd import ops
+    from test_hip_shapes import mvs_inputs
+    H, W, V, D = CONFIGS[2]
+    h, w = H // 4, W // 4
+    feats, projs, key_inv, depth = mvs_inputs(1, 32, h, w, D, V, seed=52)
+    for d0 in (0, 192):  # the near planes (gathered taps) and far ones (LDS windows)
+        got = ops.warp_variance(T(feats[0], dev), [T(f, dev) for f in feats[1:]], [T(p, dev) for p in projs], T(key_inv, dev),
+                                T(depth[:, d0:d0 + 64], dev), channels_last=True, exact_grid=True)
+        ref = CO.warp_variance(feats[0], feats[1:], projs, key_inv, depth[:, d0:d0 + 64])[0]
+        np.testing.assert_allclose(got[0].permute(3, 0, 1, 2).cpu().numpy(), ref, atol=ATOL, rtol=RTOL)
 
 
 @pytest.mark.parametrize("cfg", [1, 3])
