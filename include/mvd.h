@@ -164,7 +164,12 @@ size_t mvd_warp_variance_f16_workspace_bytes(int B);
 int mvd_warp_variance_f16(const void* key_feat, const void* const* src_feat, const float* const* src_proj,
                           const float* key_proj_inv, const float* depth_values, int B, int D, int h, int w, int V,
                           void* var_out, void* workspace, size_t workspace_bytes, mvd_stream_t stream);
-/* elementwise fp32 <-> fp16 (round to nearest even); n must be a multiple of 4 */
+/* elementwise fp32 <-> fp16 (round to nearest even); n must be a multiple of 4.
+ * Range of the fp16-feature variant (this converter, mvd_warp_variance_f16, mvd_conv3d_bn_relu_f16in): plain IEEE fp16, no
+ * scaling — |x| > 65504 becomes +-inf, |x| < 6.1e-5 loses precision (subnormal), |x| < 3e-8 becomes 0; inf / NaN propagate.
+ * FeatureNet's last convolution has no normalisation, so the magnitude of the features (and of their variance, which is
+ * stored in fp16 too) depends on the checkpoint: the variant is for feature magnitudes of O(1), as with BASELINE.json
+ * configs[3]'s weights; the fp32 path (range-scaled split first layer) has no such limit. */
 int mvd_convert_f32_to_f16(const float* src, void* dst, long long n, mvd_stream_t stream);
 int mvd_convert_f16_to_f32(const void* src, float* dst, long long n, mvd_stream_t stream);
 

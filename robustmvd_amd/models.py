@@ -151,7 +151,10 @@ class MVSNet(nn.Module):
         """half_features (an extension; the reference has no such switch): BASELINE.json configs[3] — the feature maps
         are rounded to fp16 before the sweep, the variance volume is stored fp16 and the regulariser's first layer runs
         on fp16 MFMA with fp32 accumulation; everything else (positions, blend, variance, layers 2..11, soft argmin)
-        stays fp32.  Regressed depth within rtol 1e-2 of the fp32 path."""
+        stays fp32.  Regressed depth within rtol 1e-2 of the fp32 path.  Plain IEEE fp16 without scaling:
+        feature or variance magnitudes beyond 65504 become inf (include/mvd.h); meant for O(1) features.
+        conv0_split (default True): the regulariser's first layer with split, range-scaled fp16 operands on fp16 MFMA
+        (CostRegNet); False = fp32 MFMA.  exact_grid: K3's sampling positions by the reference's own rounding chain."""
         super().__init__()
         self.half_features = bool(half_features)
         if sample_in_inv_depth_space:

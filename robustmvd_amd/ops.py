@@ -28,9 +28,17 @@ def inference_only(fn):
     call runs under torch.no_grad()."""
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
-        if torch.is_grad_enabled() and any(t.requires_grad for t in _tensors((args, kwargs))):
-            raise RuntimeError(f"{fn.__qualname__}: an input requires grad, but this HIP path is inference-only (no "
-                               "backward is implemented); call it under torch.no_grad() or detach the inputs")
+        if torch.is_grad_enabled():
+            if any(t.requires_grad for t in _tensors((args, kwargs))):
+                raise RuntimeError(f"{fn.__qualname__}: an input requires grad, but this HIP path is inference-only (no "
+                                   "backward is implemented); call it under torch.no_grad() or detach the inputs")
+            # a bound nn.Module method (FeatureNet.forward_layout, CostRegNet.forward ...): `self` carries the parameters.
+            # The reference's module is trainable; in training mode with autograd recording a silent no_grad forward would
+            # hand back graph-less outputs
+            owner = args[0] if args and isinstance(args[0], torch.nn.Module) else None
+            if owner is not None and owner.training and any(p.requires_grad for p in owner.parameters()):
+                raise RuntimeError(f"{fn.__qualname__}: the module is in training mode with trainable parameters and autograd is "
+                                   "recording, but this HIP path is inference-only; call .eval() and run it under torch.no_grad()")
         with torch.no_grad():
             return fn(*args, **kwargs)
     return wrapper

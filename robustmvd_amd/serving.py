@@ -84,7 +84,13 @@ class PinnedUploader:
             self._tensors, self._event, self._device = tensors, event, device
 
         def wait(self):
-            torch.cuda.current_stream(self._device).wait_event(self._event)
+            """Makes the CURRENT stream wait for the copy and marks the tensors as used on it (they live in the copy stream's
+            allocator pool: without record_stream the block could be handed to the next stage() while this stream still
+            reads it).  A consumer that passes the tensors on to further streams must call record_stream for those itself."""
+            cur = torch.cuda.current_stream(self._device)
+            cur.wait_event(self._event)
+            for t in self._tensors:
+                t.record_stream(cur)
             return self._tensors
 
     def __init__(self, device):
@@ -108,8 +114,6 @@ class PinnedUploader:
             dev = [t.to(self.device, non_blocking=True) for t in pinned]
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        for t in dev:  # the tensors are consumed on another stream: keep the allocator from recycling them early
-            t.record_stream(torch.cuda.current_stream(self.device))
-        staged = self._Staged(dev, ev, self.device)
+        staged = self._Staged(dev, ev, self.device)  # wait() records the consuming stream
         staged._pinned = pinned  # keep the host buffers alive until the copy has been consumed
         return staged

@@ -259,3 +259,13 @@ def test_conv0_f16_and_split_batch_of_two(dev):
     ref16 = np.stack([CO.conv3d(x16[b].astype(np.float32), wt.astype(np.float16).astype(np.float32), scale, shift, stride=1, relu=True)
                       for b in range(B)])
     np.testing.assert_allclose(got16.permute(0, 4, 1, 2, 3).cpu().numpy(), ref16, atol=1e-3, rtol=1e-3)
+
+
+def test_fp16_variant_range_is_plain_ieee(dev):
+    """the fp16-feature variant does no range handling; pin what happens outside fp16's range: saturation to inf
+    above 65504, flush below the smallest subnormal, NaN kept (include/mvd.h states it)."""
+    from robustmvd_amd import ops
+    x = torch.tensor([1.0, 65504.0, 65520.0, 1e5, -1e6, 6e-8, 2e-8, float("nan")], device=dev)
+    y = ops.to_f16(x).float().cpu().numpy()
+    assert y[0] == 1.0 and y[1] == 65504.0 and np.isinf(y[2]) and np.isinf(y[3]) and y[4] == -np.inf
+    assert y[5] == np.float32(np.float16(6e-8)) and y[6] == 0.0 and np.isnan(y[7])

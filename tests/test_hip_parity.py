@@ -415,3 +415,28 @@ def test_pinned_uploader_matches_direct_upload(dev):
             assert a.is_cuda and torch.equal(a.cpu(), torch.from_numpy(b))
     with pytest.raises(ValueError):
         R.PinnedUploader("cpu")
+
+
+def test_pinned_uploader_consumed_on_another_stream(dev):
+    """tensors staged by PinnedUploader live in the copy stream's allocator pool; wait() must record the CONSUMING
+    stream (not the stream current at stage() time), or the next stage() could recycle the block under a reader.  Stage on the
+    default stream, consume on a side stream while further frames are staged, compare with the host data."""
+    import robustmvd_amd as R
+    rng = np.random.default_rng(3)
+    frames = [[rng.uniform(0, 255, (3, 96, 128)).astype(np.float32) for _ in range(3)] for _ in range(6)]
+    up = R.PinnedUploader(dev)
+    side = torch.cuda.Stream(dev)
+    sums, nxt = [], up.stage(frames[0])
+    for i in range(len(frames)):
+        cur, nxt = nxt, up.stage(frames[(i + 1) % len(frames)])
+        with torch.cuda.stream(side):
+            imgs = cur.wait()
+            acc = torch.zeros((), device=dev, dtype=torch.float64)
+            for _ in range(20):                      # keep the side stream busy while the next frames are staged
+                acc = acc + sum(im.double().sum() for im in imgs) / 20
+            sums.append(acc)
+        del cur, imgs
+    torch.cuda.synchronize(dev)
+    for i, s_ in enumerate(sums):
+        want = sum(float(np.asarray(im, np.float64).sum()) for im in frames[i])
+        assert abs(float(s_) - want) <= 1e-9 * abs(want)

@@ -123,3 +123,18 @@ def test_inference_only_ops_refuse_autograd():
         ops.softmax_regress(x, torch.zeros(1, 4))
     # robust_mvd is trainable again (K1 / K2 have backward kernels); the MVSNet path (folded BN, HIP layers) is not
     assert R.list_models(trainable_only=True) == ["robust_mvd"]
+
+
+def test_inference_only_module_methods_refuse_training_mode():
+    """ADVICE r2: the inference-only HIP entry points are also bound nn.Module methods (CostRegNet.forward, FeatureNet ...);
+    in training mode with trainable parameters and autograd recording they must raise instead of silently returning
+    graph-less outputs (the reference's modules are trainable).  Checked before any device call, so it runs on CPU."""
+    import pytest
+    import torch
+    import robustmvd_amd as R
+    net = R.CostRegNet().train()
+    x = torch.zeros(1, 32, 8, 8, 8)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        net.forward(x)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        net.forward(x.requires_grad_())          # an input that requires grad raises as before
