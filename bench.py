@@ -267,9 +267,9 @@ def main(argv=None):
         "data": "synthetic", "settle_forwards": SETTLE_FORWARDS, "frames_of_rank0": my_frames,
         "config": {"workload": f"mvsnet (Path B) forward {H}x{W}, {V} source views, {D} planes, batch 1 per step "
                                f"(BASELINE.json configs[{args.config}])" + ("" if half else
-                               "; regulariser's first layer: every fp32 operand as two range-scaled fp16 terms on fp16 MFMA, fp32 "
-                               "accumulation (at least as close to a float64 convolution as the fp32 matrix instruction over 1e-42..1e30: "
-                               "tests/test_hip_f16.py), the other ten layers and everything else on fp32 arithmetic"),
+                               "; the regulariser's two layers with 32 input channels (conv0, conv4): every fp32 operand as two range-scaled fp16 terms "
+                               "on fp16 MFMA, fp32 accumulation (at least as close to a float64 convolution as the fp32 matrix instruction "
+                               "over 1e-42..1e30: tests/test_hip_f16.py), the other nine layers and everything else on fp32 arithmetic"),
                    "parallelism": f"{world} independent replica(s), frames round-robin, no collectives"},
     }
     if stub:
@@ -394,17 +394,18 @@ def main(argv=None):
         h2d_inclusive_block()
 
     def fp32_conv0_block():
-        """Extra, not the headline: the same forward with the regulariser's first layer on the fp32 matrix instruction
+        """Extra, not the headline: the same forward with every regulariser layer on the fp32 matrix instruction
         (MVSNet(conv0_split=False), the round-2 headline arithmetic), and the difference of the two depth maps."""
         ms, _ = build_mvsnet(D, dev, half_features=half, conv0_split=False)
         with torch.no_grad():
-            d0 = model(**samples[0])[0]["depth"]
-            d1 = ms(**samples[0])[0]["depth"]
+            d0 = model(**samples[0])[0]["depth"].clone()
+            d1 = ms(**samples[0])[0]["depth"].clone()
+        torch.cuda.synchronize(dev)
         rel = float(((d1 - d0).abs() / d0.abs()).max())
         dts = timed_loop(ms, samples, args.steps, args.warmup, world, dev, None, cdev)
         out["conv0_fp32_mfma"] = {"value": world * args.steps / dts, "unit": "depth-maps/sec", "ms_per_step": dts / args.steps * 1e3,
                                   "max_rel_depth_diff_vs_headline_model": rel,
-                                  "note": "MVSNet(conv0_split=False): first regulariser layer on v_mfma_f32_16x16x4_f32 like the other ten; "
+                                  "note": "MVSNet(conv0_split=False): the two 32-input-channel regulariser layers on v_mfma_f32_16x16x4_f32 like the other nine; "
                                           "not the headline value"}
         del ms
 

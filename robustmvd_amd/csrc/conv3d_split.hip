@@ -71,13 +71,13 @@ __global__ void conv0_split_wscale_kernel(const float* __restrict__ w, float* __
     }
 }
 
-// w (8, 32, 3, 3, 3) fp32 -> [tap 27][lane 64][8 halves]: lane l = column l%16 (0..7: w_hi of cout l%16, 8..15: w_lo of cout
-// l%16 - 8), cin 8*(l/16) .. +7; weights divided by the channel's 2^k_c first (exact)
-__global__ void pack_conv0_split_kernel(const float* __restrict__ w, const float* __restrict__ wscale, _Float16* __restrict__ packed) {
+// w (Cout, 32, 3, 3, 3) fp32 -> [cout block Cout/8][tap 27][lane 64][8 halves]: lane l = column l%16 (0..7: w_hi of cout 8 cb + l%16,
+// 8..15: w_lo of cout 8 cb + l%16 - 8), cin 8*(l/16) .. +7; weights divided by the channel's 2^k_c first (exact)
+__global__ void pack_conv0_split_kernel(const float* __restrict__ w, const float* __restrict__ wscale, _Float16* __restrict__ packed, int ncb) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= 27 * 64 * 8) return;
-    const int j = e & 7, lane = (e >> 3) & 63, tap = e >> 9;
-    const int col = lane & 15, cin = 8 * (lane >> 4) + j, cout = col & 7;
+    if (e >= ncb * 27 * 64 * 8) return;
+    const int j = e & 7, lane = (e >> 3) & 63, tap = (e >> 9) % 27, cb = (e >> 9) / 27;
+    const int col = lane & 15, cin = 8 * (lane >> 4) + j, cout = cb * 8 + (col & 7);
     const float v = w[((size_t)cout * 32 + cin) * 27 + tap] / wscale[cout];
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
@@ -90,8 +90,9 @@ struct SplitParams {
     const float* scale;
     const float* shift;
     const float* absmax;  // max |x| (device, one float): sets the activations' power-of-two scale
-    float* y;             // (B, D, h, w, 8) fp32
+    float* y;             // (B, D, h, w, Cout) fp32
     int B, D, h, w, relu;
+    int cout, ncb;        // output channels (a multiple of 8) and Cout / 8: one workgroup computes 8 of them
     int tiles_x, tiles_y, dgroups, td, tiles_per_xcd;
 };
 
@@ -116,6 +117,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     // the halo rows and columns that neighbouring tiles share are re-read from ONE L2 instead of from HBM by eight
     const int xcd = blockIdx.x & 7;
     int j = blockIdx.x >> 3;
+    const int cb = j % p.ncb; j /= p.ncb;  // the cout blocks of a tile run next to each other: they read the same input through one L2
     const int t_in = j % p.tiles_per_xcd; j /= p.tiles_per_xcd;
     const int dg = j % p.dgroups;
     const int b = j / p.dgroups;
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 
     h16x8 wf[27];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) wf[t] = *reinterpret_cast<const h16x8*>(p.wpk + ((size_t)t * 64 + lane) * 16);
+    for (int t = 0; t < 27; ++t) wf[t] = *reinterpret_cast<const h16x8*>(p.wpk + (((size_t)cb * 27 + t) * 64 + lane) * 16);
 
     // staging map: item e = tid + 256 k -> (row, col, 8-channel chunk).  Everything below is branch-free: a voxel outside the
     // plane (or a plane outside the volume) is an out-of-range buffer offset (reads 0), the 208 idle items of the last round
@@ -205,8 +207,8 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 
     // epilogue constants of the lanes that end up with a result: column (cout) l%16 < 8
     const int col = lane & 15;
-    float esc_ = p.scale[col & 7], esh_ = p.shift[col & 7];
-    float eun_ = reinterpret_cast<const float*>(p.wpk + 27 * 64 * 16)[col & 7] * xs_inv;  // 2^(k_c + e): undoes both scalings
+    float esc_ = p.scale[cb * 8 + (col & 7)], esh_ = p.shift[cb * 8 + (col & 7)];
+    float eun_ = reinterpret_cast<const float*>(p.wpk + (size_t)p.ncb * 27 * 64 * 16)[cb * 8 + (col & 7)] * xs_inv;  // 2^(k_c + e): undoes both scalings
     const float floor_ = p.relu ? 0.f : -__builtin_inff();
     const int xh = wv & 1, rp = wv >> 1;
 
@@ -229,10 +231,11 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 #pragma unroll
     for (int row = 0; row < 2; ++row) {
         const int oy = y0 + 2 * rp + row;
-        yoff[row] = (col < 8 && oy < h) ? (unsigned)((((size_t)oy * w + x0 + 16 * xh + 4 * (lane >> 4)) * 8 + col) * 4) : OOB;
+        yoff[row] = (col < 8 && oy < h) ? (unsigned)((((size_t)oy * w + x0 + 16 * xh + 4 * (lane >> 4)) * p.cout + cb * 8 + col) * 4) : OOB;
     }
     const int oxb = x0 + 16 * xh + 4 * (lane >> 4);
-    const size_t yplane_f = (size_t)h * w * 8;
+    const size_t yplane_f = (size_t)h * w * p.cout;
+    const unsigned vox_b = (unsigned)p.cout * 4u;  // bytes from one output voxel to the next
 
     fetch(dz0 - 1);
     asm volatile("" : "+v"(esc_), "+v"(esh_), "+v"(eun_));  // the per-lane epilogue constants have landed: no vmcnt wait inside the loop
@@ -316,7 +319,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
                 float r = __builtin_fmaf(cur + acc[0][row][1][i], 1.0f / 2048.0f, acc[0][row][0][i]);
                 r = fmaxf(__builtin_fmaf(r * eun_, esc_, esh_), floor_);
                 if (!(SPLIT_KO & 2) || r == 12345.678f)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs_out, ox + i < w ? yoff[row] + 32u * i : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs_out, ox + i < w ? yoff[row] + vox_b * i : OOB, 0, 0);
             } else if (!(SPLIT_KO & 4)) {  // staging of plane z+1 / reload with plane z+2: item k, float pair q of its 4
                 const int k = (g - 8) >> 2, q = (g - 8) & 3;
                 const sf32x4 v = __builtin_bit_cast(sf32x4, pre[k][q >> 1]);
@@ -351,36 +354,43 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 
 extern "C" {
 
-size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout) { return (Cin == 32 && Cout == 8) ? (size_t)27 * 64 * 16 + 8 * sizeof(float) : 0; }
+size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout) {
+    return (Cin == 32 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0) ? (size_t)(Cout / 8) * 27 * 64 * 16 + (size_t)Cout * sizeof(float) : 0;
+}
 
 int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream) {
     MVD_REQUIRE(w && packed, "pack_conv3d_weights_split: NULL argument");
-    MVD_REQUIRE(Cin == 32 && Cout == 8, "pack_conv3d_weights_split: only the 32 -> 8 first layer of CostRegNet is built (got %d -> %d)", Cin, Cout);
-    float* wscale = reinterpret_cast<float*>(static_cast<char*>(packed) + (size_t)27 * 64 * 16);
-    hipLaunchKernelGGL(mvd::conv0_split_wscale_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, w, wscale);
-    hipLaunchKernelGGL(mvd::pack_conv0_split_kernel, dim3((27 * 64 * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wscale,
-                       (_Float16*)packed);
+    MVD_REQUIRE(Cin == 32 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0,
+                "pack_conv3d_weights_split: 32 input channels and 8, 16, ... 64 output channels are built (got %d -> %d)", Cin, Cout);
+    const int ncb = Cout / 8;
+    float* wscale = reinterpret_cast<float*>(static_cast<char*>(packed) + (size_t)ncb * 27 * 64 * 16);
+    hipLaunchKernelGGL(mvd::conv0_split_wscale_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, wscale);
+    hipLaunchKernelGGL(mvd::pack_conv0_split_kernel, dim3((ncb * 27 * 64 * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wscale,
+                       (_Float16*)packed, ncb);
     return mvd::launch_status("pack_conv3d_weights_split");
 }
 
 int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
                                  float* y, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream) {
     MVD_REQUIRE(x && x_absmax && packed_w && scale && shift && y, "conv3d_split: NULL argument");
-    MVD_REQUIRE(Cin == 32 && Cout == 8, "conv3d_split: only the 32 -> 8 first layer of CostRegNet is built (got %d -> %d)", Cin, Cout);
+    MVD_REQUIRE(Cin == 32 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0,
+                "conv3d_split: 32 input channels and 8, 16, ... 64 output channels are built (got %d -> %d)", Cin, Cout);
     MVD_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "conv3d_split: non-positive dimension");
-    MVD_REQUIRE((long long)h * w * 128 < 0x7fffffffLL, "conv3d_split: one input plane exceeds the 31-bit byte-offset range");
+    MVD_REQUIRE((long long)h * w * 128 < 0x7fffffffLL && (long long)h * w * Cout * 4 < 0x7fffffffLL,
+                "conv3d_split: one plane exceeds the 31-bit byte-offset range");
     mvd::SplitParams p{};
     p.x = x; p.absmax = x_absmax; p.wpk = (const char*)packed_w; p.scale = scale; p.shift = shift; p.y = y;
     p.B = B; p.D = D; p.h = h; p.w = w; p.relu = relu;
+    p.cout = Cout; p.ncb = Cout / 8;
     p.tiles_x = (w + mvd::S_TW - 1) / mvd::S_TW;
     p.tiles_y = (h + mvd::S_TH - 1) / mvd::S_TH;
     const long long tiles = (long long)p.tiles_x * p.tiles_y;
     p.tiles_per_xcd = (int)((tiles + 7) / 8);
     int td = 32;
-    while (td > 8 && tiles * B * ((D + td - 1) / td) < 2048) td /= 2;
+    while (td > 8 && tiles * B * p.ncb * ((D + td - 1) / td) < 2048) td /= 2;
     p.td = td;
     p.dgroups = (D + td - 1) / td;
-    const long long nblk = 8LL * p.tiles_per_xcd * p.dgroups * B;
+    const long long nblk = 8LL * p.ncb * p.tiles_per_xcd * p.dgroups * B;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv3d_split: %lld workgroups exceed the grid limit", nblk);
     const size_t lds = 2 * (size_t)mvd::S_PLANE_BYTES + 256 * 16;  // two slots + the dump row
     (void)hipFuncSetAttribute((const void*)mvd::conv0_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

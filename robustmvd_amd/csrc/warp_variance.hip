@@ -1244,6 +1244,7 @@ __device__ __forceinline__ float finite_abs_or_zero(float v) {
     return a <= 3.402823466e38f ? a : 0.f;  // false for inf and NaN
 }
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    __shared__ float wmax[4];
     const long long n4 = n / 4, stride = (long long)gridDim.x * 256;
     float m = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -1252,14 +1253,20 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) m = fmaxf(m, finite_abs_or_zero(x[n4 * 4 + threadIdx.x]));
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // ONE atomic per workgroup: atomics on a single address serialise at ~10 ns each
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
 }
 
 int absmax_launch(const float* x, long long n, float* absmax, hipStream_t st) {
     if (hipMemsetAsync(absmax, 0, sizeof(float), st) != hipSuccess) return launch_status("absmax: memset");
     if (n <= 0) return MVD_OK;
     const long long want = (n / 4 + 255) / 256;
-    const unsigned nblk = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+    const unsigned nblk = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));  // 8 workgroups per CU, grid-stride
     hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(absmax));
     return launch_status("absmax");
 }

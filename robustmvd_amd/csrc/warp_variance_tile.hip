@@ -571,12 +571,17 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParam
         }
     }
 #undef MVD_UNIT_BARRIER
-    if (want_absmax) {  // non-negative floats order like their bit patterns
+    if (want_absmax) {  // non-negative floats order like their bit patterns; one global atomic per workgroup (atomics on one
+        // address serialise), the four waves meet in an LDS word that no later code reads
         unsigned m = __float_as_uint(amax);
         m = max(m, row_shr<1>(m)); m = max(m, row_shr<2>(m)); m = max(m, row_shr<4>(m)); m = max(m, row_shr<8>(m));
         m = max(m, (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x142, 0xa, 0xf, false));
         m = max(m, (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x143, 0xc, 0xf, false));
-        if ((tid & 63) == 63) atomicMax(reinterpret_cast<unsigned*>(p.absmax), m);
+        unsigned* wm = reinterpret_cast<unsigned*>(lds + PROBE0);
+        __syncthreads();  // every wave is past its last use of the probe words
+        if ((tid & 63) == 63) wm[wv] = m;
+        __syncthreads();
+        if (tid == 0) atomicMax(reinterpret_cast<unsigned*>(p.absmax), max(max(wm[0], wm[1]), max(wm[2], wm[3])));
     }
 }
 
