@@ -405,7 +405,7 @@ def main(argv=None):
         dts = timed_loop(ms, samples, args.steps, args.warmup, world, dev, None, cdev)
         out["conv0_fp32_mfma"] = {"value": world * args.steps / dts, "unit": "depth-maps/sec", "ms_per_step": dts / args.steps * 1e3,
                                   "max_rel_depth_diff_vs_headline_model": rel,
-                                  "note": "MVSNet(conv0_split=False): the two 32-input-channel regulariser layers on v_mfma_f32_16x16x4_f32 like the other nine; "
+                                  "note": "MVSNet(conv0_split=False): conv0, conv2 and conv4 on v_mfma_f32_16x16x4_f32 like the other eight layers; "
                                           "not the headline value"}
         del ms
 

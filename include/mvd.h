@@ -218,8 +218,9 @@ int mvd_conv3d_bn_relu_f16in(const void* x, const void* packed_w, const float* s
  * `x_absmax`, a DEVICE pointer to one float holding max |x| over the whole input (mvd_absmax_f32, or the by-product of
  * mvd_warp_variance_absmax_f32); any upper bound is safe, a tight one most precise: a value v is represented to
  * |error| <= max(2^-22 |v|, 2^-50 max|x|).  inf / NaN inputs give inf / NaN outputs where they reach, as on fp32.
- * x (B,D,h,w,32) fp32 -> y (B,D,h,w,Cout) fp32; Cin = 32, Cout = 8, 16, ... 64 (a workgroup computes 8 output channels of its
- * tile; the regulariser's conv0 (32 -> 8) and conv4 (32 -> 32) use it). */
+ * x (B,D,h,w,Cin) fp32 -> y (B,D,h,w,Cout) fp32; Cin = 16 or 32, Cout = 8, 16, ... 64 (a workgroup computes 8 output channels
+ * of its tile; the regulariser's conv0 (32 -> 8), conv2 (16 -> 16) and conv4 (32 -> 32) use it).  With 16 input channels a
+ * 64-byte MFMA fragment spans two x-adjacent voxels: the kw taps go in pairs (0,1), (2, zero weights). */
 size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout);
 int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream);
 int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,

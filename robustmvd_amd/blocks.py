@@ -261,8 +261,8 @@ class CostRegNet(nn.Module):
     UPS = [("conv7", 64, 32), ("conv9", 32, 16), ("conv11", 16, 8)]
 
     def __init__(self, conv0_split=True):
-        """conv0_split (default on): the fp32 operands of the two layers with 32 input channels (conv0: 32 -> 8 at full
-        resolution, conv4: 32 -> 32) are split into two fp16 terms each, after an exact
+        """conv0_split (default on): the fp32 operands of the stride-1 layers with 16 or 32 input channels (conv0: 32 -> 8 at
+        full resolution, conv2: 16 -> 16, conv4: 32 -> 32) are split into two fp16 terms each, after an exact
         power-of-two range scaling, and multiplied on fp16 MFMA with fp32 accumulation (ops.conv3d_bn_relu_split); its
         results are at least as close to the exact convolution as the fp32 matrix instruction's (measured against a
         float64 oracle over magnitudes 1e-30 .. 1e30: tests/test_hip_f16.py).  False: every layer on fp32 MFMA."""
@@ -297,9 +297,9 @@ class CostRegNet(nn.Module):
         pk["prob"] = (w, 8, 1, torch.ones(1, device=w.device), self.prob.bias.detach().contiguous(), L.CONV3D_STRIDE1)
         # fp16-feature variant (BASELINE configs[3]): conv0's weights rounded to fp16 in fp16-MFMA fragment order
         pk["conv0_f16"] = ops.pack_conv3d_weights_f16(self.conv0.conv.weight.detach())
-        if self.conv0_split:  # both layers with 32 input channels take the split-operand kernel
-            pk["conv0_split"] = ops.pack_conv3d_weights_split(self.conv0.conv.weight.detach())
-            pk["conv4_split"] = ops.pack_conv3d_weights_split(self.conv4.conv.weight.detach())
+        if self.conv0_split:  # the stride-1 layers with 16 or 32 input channels take the split-operand kernel
+            for name in ("conv0", "conv2", "conv4"):
+                pk[name + "_split"] = ops.pack_conv3d_weights_split(getattr(self, name).conv.weight.detach())
         self._packed, self._packed_key = pk, key
         return pk
 
@@ -324,14 +324,14 @@ class CostRegNet(nn.Module):
             conv0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True, x_absmax=x_absmax)
         else:
             conv0 = layer("conv0", x)
-        conv2 = layer("conv2", layer("conv1", conv0))
-        conv3 = layer("conv3", conv2)
-        if self.conv0_split:  # 32 -> 32 at quarter resolution: the split kernel, 8 output channels per workgroup; max |x| by a pass over 28 MB
-            _, _, _, scale4, shift4, _ = pk["conv4"]
-            conv4 = ops.conv3d_bn_relu_split(conv3, pk["conv4_split"], scale4, shift4, relu=True)
-        else:
-            conv4 = layer("conv4", conv3)
-        del conv3
+        def split_or_fp32(name, t):  # conv2 (16 -> 16), conv4 (32 -> 32): 8 output channels per workgroup; max |x| by a pass over the (small) input
+            if not self.conv0_split:
+                return layer(name, t)
+            _, _, _, sc, sh, _ = pk[name]
+            return ops.conv3d_bn_relu_split(t, pk[name + "_split"], sc, sh, relu=True)
+
+        conv2 = split_or_fp32("conv2", layer("conv1", conv0))
+        conv4 = split_or_fp32("conv4", layer("conv3", conv2))
         y = layer("conv6", layer("conv5", conv4))
         y = layer("conv7", y, skip=conv4)
         del conv4

@@ -43,19 +43,32 @@ typedef unsigned int su32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int su32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int S_TH = 4, S_TW = 32, S_ROWS = S_TH + 2, S_COLS = S_TW + 2;
-constexpr int S_HALF_BYTES = S_ROWS * S_COLS * 64;      // hi (or lo) part of one staged plane
-constexpr int S_PLANE_BYTES = 2 * S_HALF_BYTES;
-constexpr int S_ITEMS = S_ROWS * S_COLS * 4;             // (voxel, 8-channel chunk) items per plane
-constexpr int S_NLOAD = (S_ITEMS + 255) / 256;
+constexpr int S_TH = 4, S_TW = 32, S_ROWS = S_TH + 2;
+// geometry by input channel count.  CIN = 32: one voxel's channels are one MFMA K (64 bytes per term), three fragments per
+// (kd, kh) — one per kw.  CIN = 16: a 64-byte fragment spans TWO x-adjacent voxels, so the kw taps go in pairs (0,1), (2, zero
+// weights): two fragments per (kd, kh); the staged tile gets a 35th, always-zero column for the pad tap to read.
+template <int CIN>
+struct SplitGeom {
+    static constexpr int CH8 = CIN / 8;                         // 8-channel chunks per voxel
+    static constexpr int VB = CIN * 2;                          // bytes per voxel and term
+    static constexpr int KWG = CIN == 32 ? 3 : 2;               // fragments per (kd, kh)
+    static constexpr int NT = 9 * KWG;                          // weight fragments per cout block
+    static constexpr int COLS = CIN == 32 ? S_TW + 2 : S_TW + 3;
+    static constexpr int HALF_BYTES = S_ROWS * COLS * VB;       // hi (or lo) part of one staged plane
+    static constexpr int PLANE_BYTES = 2 * HALF_BYTES;
+    static constexpr int ITEMS = S_ROWS * COLS * CH8;           // (voxel, 8-channel chunk) items per plane
+    static constexpr int NLOAD = (ITEMS + 255) / 256;
+    static constexpr int NF = 4 * KWG * 2;                      // fragments per pass: input rows x kw groups x terms
+    static_assert(NF - 8 == 4 * NLOAD, "pass B interleaves 8 epilogue groups and 4 staging groups per item");
+};
 
 // per output channel: 2^k_c with k_c = exponent(max |w_c|) - 10 (0 for an all-zero channel), appended to the packed buffer
-__global__ void conv0_split_wscale_kernel(const float* __restrict__ w, float* __restrict__ wscale) {
+__global__ void conv0_split_wscale_kernel(const float* __restrict__ w, float* __restrict__ wscale, int cin) {
     __shared__ float red[256];
     const int c = blockIdx.x;
     float m = 0.f;
-    for (int e = threadIdx.x; e < 32 * 27; e += 256) {
-        const float v = fabsf(w[(size_t)c * 32 * 27 + e]);
+    for (int e = threadIdx.x; e < cin * 27; e += 256) {
+        const float v = fabsf(w[(size_t)c * cin * 27 + e]);
         m = (v <= 3.4e38f && v > m) ? v : m;  // finite values only
     }
     red[threadIdx.x] = m;
@@ -71,14 +84,21 @@ __global__ void conv0_split_wscale_kernel(const float* __restrict__ w, float* __
     }
 }
 
-// w (Cout, 32, 3, 3, 3) fp32 -> [cout block Cout/8][tap 27][lane 64][8 halves]: lane l = column l%16 (0..7: w_hi of cout 8 cb + l%16,
-// 8..15: w_lo of cout 8 cb + l%16 - 8), cin 8*(l/16) .. +7; weights divided by the channel's 2^k_c first (exact)
+// w (Cout, CIN, 3, 3, 3) fp32 -> [cout block Cout/8][fragment NT][lane 64][8 halves]: lane l = column l%16 (0..7: w_hi of cout
+// 8 cb + l%16, 8..15: w_lo of cout 8 cb + l%16 - 8), K values 8*(l/16) .. +7 of the fragment: CIN = 32: fragment = tap, K = cin;
+// CIN = 16: fragment = (kd, kh, kw pair g), K = 16 * (kw - 2g) + cin, kw = 3 is the zero pad.  Weights divided by the
+// channel's 2^k_c first (exact).
+template <int CIN>
 __global__ void pack_conv0_split_kernel(const float* __restrict__ w, const float* __restrict__ wscale, _Float16* __restrict__ packed, int ncb) {
+    using G = SplitGeom<CIN>;
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= ncb * 27 * 64 * 8) return;
-    const int j = e & 7, lane = (e >> 3) & 63, tap = (e >> 9) % 27, cb = (e >> 9) / 27;
-    const int col = lane & 15, cin = 8 * (lane >> 4) + j, cout = cb * 8 + (col & 7);
-    const float v = w[((size_t)cout * 32 + cin) * 27 + tap] / wscale[cout];
+    if (e >= ncb * G::NT * 64 * 8) return;
+    const int j = e & 7, lane = (e >> 3) & 63, t = (e >> 9) % G::NT, cb = (e >> 9) / G::NT;
+    const int col = lane & 15, k = 8 * (lane >> 4) + j, cout = cb * 8 + (col & 7);
+    int tap, cin;
+    if constexpr (CIN == 32) { tap = t; cin = k; }
+    else { const int kw = 2 * (t % 2) + k / 16; tap = kw < 3 ? (t / 2) * 3 + kw : -1; cin = k % 16; }
+    const float v = tap >= 0 ? w[((size_t)cout * CIN + cin) * 27 + tap] / wscale[cout] : 0.0f;
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
     packed[e] = col < 8 ? hi : lo;
@@ -108,7 +128,11 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 // clocks of MFMA and the kernel sat on the LDS port at 35 % matrix utilisation.  Three output planes of accumulators are in
 // flight per wave (48 VGPRs); the LDS holds two plane slots (the one being read, the one being written).
 // wave wv: columns 16 (wv & 1) .. +15, output rows 2 (wv >> 1), +1 of the 4 x 32 tile.
+template <int CIN>
 __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
+    using G = SplitGeom<CIN>;
+    constexpr int S_COLS = G::COLS, S_HALF_BYTES = G::HALF_BYTES, S_PLANE_BYTES = G::PLANE_BYTES, S_ITEMS = G::ITEMS, S_NLOAD = G::NLOAD;
+    constexpr int KWG = G::KWG, NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) char ring[];  // 2 planes x (hi part | lo part)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int D = p.D, h = p.h, w = p.w;
@@ -127,9 +151,9 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     const int x0 = tx * S_TW, y0 = ty * S_TH;
     const int dz0 = dg * p.td, dz1 = min(dz0 + p.td, D);
 
-    h16x8 wf[27];
+    h16x8 wf[NT];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) wf[t] = *reinterpret_cast<const h16x8*>(p.wpk + (((size_t)cb * 27 + t) * 64 + lane) * 16);
+    for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const h16x8*>(p.wpk + (((size_t)cb * NT + t) * 64 + lane) * 16);
 
     // staging map: item e = tid + 256 k -> (row, col, 8-channel chunk).  Everything below is branch-free: a voxel outside the
     // plane (or a plane outside the volume) is an out-of-range buffer offset (reads 0), the 208 idle items of the last round
@@ -141,14 +165,15 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 #pragma unroll
     for (int k = 0; k < S_NLOAD; ++k) {
         const int e = tid + 256 * k;
-        const int vox = e >> 2, ch = e & 3;
+        const int vox = e / G::CH8, ch = e % G::CH8;
         const int r = vox / S_COLS, c = vox - r * S_COLS;
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        const bool in = e < S_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        gob[k] = in ? (unsigned)(((gy * w + gx) * 32 + ch * 8) * 4) : OOB;                  // bytes inside a plane
-        loff[k] = e < S_ITEMS ? (vox * 64 + ((ch ^ ((c >> 1) & 3)) * 16)) : -1;             // swizzled as in conv0_f16
+        const bool in = e < S_ITEMS && c < S_TW + 2 && gy >= 0 && gy < h && gx >= 0 && gx < w;  // (the 35th column of CIN = 16 stays zero)
+        gob[k] = in ? (unsigned)(((gy * w + gx) * CIN + ch * 8) * 4) : OOB;                 // bytes inside a plane
+        if constexpr (CIN == 32) loff[k] = e < S_ITEMS ? (vox * 64 + ((ch ^ ((c >> 1) & 3)) * 16)) : -1;  // swizzled as in conv0_f16
+        else loff[k] = e < S_ITEMS ? e * 16 : -1;  // 32 bytes per voxel: fragment reads are conflict-free as they stand
     }
-    const size_t plane_f = (size_t)h * w * 32;
+    const size_t plane_f = (size_t)h * w * CIN;
     const float* xb = p.x + (size_t)b * D * plane_f;
     su32x4 pre[S_NLOAD][2];
     auto fetch = [&](int d) {
@@ -208,15 +233,20 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     // epilogue constants of the lanes that end up with a result: column (cout) l%16 < 8
     const int col = lane & 15;
     float esc_ = p.scale[cb * 8 + (col & 7)], esh_ = p.shift[cb * 8 + (col & 7)];
-    float eun_ = reinterpret_cast<const float*>(p.wpk + (size_t)p.ncb * 27 * 64 * 16)[cb * 8 + (col & 7)] * xs_inv;  // 2^(k_c + e): undoes both scalings
+    float eun_ = reinterpret_cast<const float*>(p.wpk + (size_t)p.ncb * NT * 64 * 16)[cb * 8 + (col & 7)] * xs_inv;  // 2^(k_c + e): undoes both scalings
     const float floor_ = p.relu ? 0.f : -__builtin_inff();
     const int xh = wv & 1, rp = wv >> 1;
 
-    int fragk[3];
+    int fragk[KWG];
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-        const int c = 16 * xh + (lane & 15) + kw;
-        fragk[kw] = (2 * rp * S_COLS + c) * 64 + (((lane >> 4) ^ ((c >> 1) & 3)) * 16);
+    for (int kw = 0; kw < KWG; ++kw) {
+        if constexpr (CIN == 32) {
+            const int c = 16 * xh + (lane & 15) + kw;
+            fragk[kw] = (2 * rp * S_COLS + c) * 64 + (((lane >> 4) ^ ((c >> 1) & 3)) * 16);
+        } else {  // kw pair: K slices 0,1 = voxel c, slices 2,3 = voxel c + 1 (32 bytes further)
+            const int c = 16 * xh + (lane & 15) + 2 * kw;
+            fragk[kw] = (2 * rp * S_COLS + c) * 32 + (lane >> 4) * 16;
+        }
     }
 
     // acc[plane slot][row][term]: slot 0 = output plane z-1 (finishes in this step), 1 = plane z, 2 = plane z+1 (starts)
@@ -269,27 +299,27 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
         asm volatile("" : "+v"(ox));  // opaque: keeps the eight store offsets from being hoisted into eight live VGPRs
 
         // read i = pass * 24 + fragment; reads pipelined DEPTH deep by hand
-        constexpr int NF = 24, NR = 2 * NF, DEPTH = SPLIT_DEPTH;
+        constexpr int NF = G::NF, NR = 2 * NF, DEPTH = SPLIT_DEPTH;
         h16x8 fr[DEPTH];
         auto rr_of = [](int ro) { return ro == 0 ? 1 : ro == 1 ? 2 : ro == 2 ? 0 : 3; };
         auto frag = [&](int i) {
-            const int g = i % NF, term = g & 1, kw = (g >> 1) % 3, rr = rr_of(g / 6);
-            if (SPLIT_KO & 32) return wf[i % 27];
-            return *reinterpret_cast<const h16x8*>(slot + term * S_HALF_BYTES + fragk[kw] + rr * S_COLS * 64);
+            const int g = i % NF, term = g & 1, kw = (g >> 1) % KWG, rr = rr_of(g / (2 * KWG));
+            if (SPLIT_KO & 32) return wf[i % NT];
+            return *reinterpret_cast<const h16x8*>(slot + term * S_HALF_BYTES + fragk[kw] + rr * S_COLS * G::VB);
         };
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) fr[i] = frag(i);
         // ---- pass A
 #pragma unroll
         for (int g = 0; g < NF; ++g) {
-            const int term = g & 1, kw = (g >> 1) % 3, rr = rr_of(g / 6);
+            const int term = g & 1, kw = (g >> 1) % KWG, rr = rr_of(g / (2 * KWG));
             const h16x8 f = fr[g % DEPTH];
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
                 const int kh = rr - row;
                 if (kh < 0 || kh > 2) continue;
-                if (SPLIT_KO & 16) acc[0][row][term][0] += f[0] * wf[18 + kh * 3 + kw][0];
-                else acc[0][row][term] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, wf[18 + kh * 3 + kw], acc[0][row][term], 0, 0, 0);
+                if (SPLIT_KO & 16) acc[0][row][term][0] += f[0] * wf[(6 + kh) * KWG + kw][0];
+                else acc[0][row][term] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, wf[(6 + kh) * KWG + kw], acc[0][row][term], 0, 0, 0);
             }
             fr[g % DEPTH] = frag(g + DEPTH);
             __builtin_amdgcn_sched_barrier(0);
@@ -300,7 +330,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
         unsigned hq0 = 0, lq0 = 0;
 #pragma unroll
         for (int g = 0; g < NF; ++g) {
-            const int term = g & 1, kw = (g >> 1) % 3, rr = rr_of(g / 6);
+            const int term = g & 1, kw = (g >> 1) % KWG, rr = rr_of(g / (2 * KWG));
             const h16x8 f = fr[(NF + g) % DEPTH];
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
@@ -308,8 +338,8 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
                 if (kh < 0 || kh > 2) continue;
 #pragma unroll
                 for (int s = 1; s < 3; ++s)  // plane slot s takes tap kd = 2 - s
-                    if (SPLIT_KO & 16) acc[s][row][term][0] += f[0] * wf[(2 - s) * 9 + kh * 3 + kw][0];
-                    else acc[s][row][term] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, wf[(2 - s) * 9 + kh * 3 + kw], acc[s][row][term], 0, 0, 0);
+                    if (SPLIT_KO & 16) acc[s][row][term][0] += f[0] * wf[((2 - s) * 3 + kh) * KWG + kw][0];
+                    else acc[s][row][term] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, wf[((2 - s) * 3 + kh) * KWG + kw], acc[s][row][term], 0, 0, 0);
             }
             if (NF + g + DEPTH < NR) fr[(NF + g) % DEPTH] = frag(NF + g + DEPTH);
             if (g < 8) {  // epilogue value g of the finished plane
@@ -352,31 +382,41 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 
 }  // namespace mvd
 
+static bool split_shape_ok(int Cin, int Cout) { return (Cin == 32 || Cin == 16) && Cout >= 8 && Cout <= 64 && Cout % 8 == 0; }
+static size_t split_frag_bytes(int Cin, int Cout) { return (size_t)(Cout / 8) * (Cin == 32 ? 27 : 18) * 64 * 16; }
+
+template <int CIN>
+static int launch_split(const mvd::SplitParams& p, long long nblk, hipStream_t st) {
+    const size_t lds = 2 * (size_t)mvd::SplitGeom<CIN>::PLANE_BYTES + 256 * 16;  // two slots + the dump row
+    (void)hipFuncSetAttribute((const void*)mvd::conv0_split_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mvd::conv0_split_kernel<CIN>, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    return mvd::launch_status("conv3d_split");
+}
+
 extern "C" {
 
 size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout) {
-    return (Cin == 32 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0) ? (size_t)(Cout / 8) * 27 * 64 * 16 + (size_t)Cout * sizeof(float) : 0;
+    return split_shape_ok(Cin, Cout) ? split_frag_bytes(Cin, Cout) + (size_t)Cout * sizeof(float) : 0;
 }
 
 int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream) {
     MVD_REQUIRE(w && packed, "pack_conv3d_weights_split: NULL argument");
-    MVD_REQUIRE(Cin == 32 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0,
-                "pack_conv3d_weights_split: 32 input channels and 8, 16, ... 64 output channels are built (got %d -> %d)", Cin, Cout);
+    MVD_REQUIRE(split_shape_ok(Cin, Cout), "pack_conv3d_weights_split: 16 or 32 input channels and 8, 16, ... 64 output channels are built (got %d -> %d)", Cin, Cout);
     const int ncb = Cout / 8;
-    float* wscale = reinterpret_cast<float*>(static_cast<char*>(packed) + (size_t)ncb * 27 * 64 * 16);
-    hipLaunchKernelGGL(mvd::conv0_split_wscale_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, wscale);
-    hipLaunchKernelGGL(mvd::pack_conv0_split_kernel, dim3((ncb * 27 * 64 * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wscale,
-                       (_Float16*)packed, ncb);
+    float* wscale = reinterpret_cast<float*>(static_cast<char*>(packed) + split_frag_bytes(Cin, Cout));
+    hipLaunchKernelGGL(mvd::conv0_split_wscale_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, wscale, Cin);
+    const unsigned nb = (unsigned)((split_frag_bytes(Cin, Cout) / 2 + 255) / 256);
+    if (Cin == 32) hipLaunchKernelGGL(mvd::pack_conv0_split_kernel<32>, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wscale, (_Float16*)packed, ncb);
+    else hipLaunchKernelGGL(mvd::pack_conv0_split_kernel<16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wscale, (_Float16*)packed, ncb);
     return mvd::launch_status("pack_conv3d_weights_split");
 }
 
 int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
                                  float* y, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream) {
     MVD_REQUIRE(x && x_absmax && packed_w && scale && shift && y, "conv3d_split: NULL argument");
-    MVD_REQUIRE(Cin == 32 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0,
-                "conv3d_split: 32 input channels and 8, 16, ... 64 output channels are built (got %d -> %d)", Cin, Cout);
+    MVD_REQUIRE(split_shape_ok(Cin, Cout), "conv3d_split: 16 or 32 input channels and 8, 16, ... 64 output channels are built (got %d -> %d)", Cin, Cout);
     MVD_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "conv3d_split: non-positive dimension");
-    MVD_REQUIRE((long long)h * w * 128 < 0x7fffffffLL && (long long)h * w * Cout * 4 < 0x7fffffffLL,
+    MVD_REQUIRE((long long)h * w * Cin * 4 < 0x7fffffffLL && (long long)h * w * Cout * 4 < 0x7fffffffLL,
                 "conv3d_split: one plane exceeds the 31-bit byte-offset range");
     mvd::SplitParams p{};
     p.x = x; p.absmax = x_absmax; p.wpk = (const char*)packed_w; p.scale = scale; p.shift = shift; p.y = y;
@@ -392,9 +432,6 @@ int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const vo
     p.dgroups = (D + td - 1) / td;
     const long long nblk = 8LL * p.ncb * p.tiles_per_xcd * p.dgroups * B;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv3d_split: %lld workgroups exceed the grid limit", nblk);
-    const size_t lds = 2 * (size_t)mvd::S_PLANE_BYTES + 256 * 16;  // two slots + the dump row
-    (void)hipFuncSetAttribute((const void*)mvd::conv0_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mvd::conv0_split_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, p);
-    return mvd::launch_status("conv3d_split");
+    return Cin == 32 ? launch_split<32>(p, nblk, (hipStream_t)stream) : launch_split<16>(p, nblk, (hipStream_t)stream);
 }
 }

@@ -382,37 +382,37 @@ def conv3d_bn_relu_f16in(x, packed, scale, shift, relu=True):
 
 @inference_only
 def pack_conv3d_weights_split(weight):
-    """weight: Conv3d (Cout,32,3,3,3) fp32, Cout in 8, 16, ... 64 -> per block of 8 output channels the [w_hi | w_lo] fp16
-    fragments for conv3d_bn_relu_split, followed by the channels' power-of-two scales."""
+    """weight: Conv3d (Cout,Cin,3,3,3) fp32, Cin 16 or 32, Cout in 8, 16, ... 64 -> per block of 8 output channels the
+    [w_hi | w_lo] fp16 fragments for conv3d_bn_relu_split, followed by the channels' power-of-two scales."""
     lib = L.load()
     wt = L.as_f32(weight, "weight")
-    cout = wt.shape[0] if wt.dim() == 5 else 0
-    if wt.dim() != 5 or tuple(wt.shape[1:]) != (32, 3, 3, 3) or cout % 8 or not 8 <= cout <= 64:
-        raise ValueError(f"conv3d split: 32 input channels and 8..64 output channels (a multiple of 8) are built, got weight {tuple(wt.shape)}")
-    packed = torch.empty(lib.mvd_conv3d_split_packed_weight_bytes(32, cout), dtype=torch.uint8, device=wt.device)
+    cout, cin = (wt.shape[0], wt.shape[1]) if wt.dim() == 5 else (0, 0)
+    if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3) or cin not in (16, 32) or cout % 8 or not 8 <= cout <= 64:
+        raise ValueError(f"conv3d split: 16 or 32 input channels and 8..64 output channels (a multiple of 8) are built, got weight {tuple(wt.shape)}")
+    packed = torch.empty(lib.mvd_conv3d_split_packed_weight_bytes(cin, cout), dtype=torch.uint8, device=wt.device)
     with torch.cuda.device(wt.device):
-        rc = lib.mvd_pack_conv3d_weights_split(L.ptr(wt), 32, cout, L.ptr(packed), L.stream_of(wt))
+        rc = lib.mvd_pack_conv3d_weights_split(L.ptr(wt), cin, cout, L.ptr(packed), L.stream_of(wt))
     L.check(rc, "mvd_pack_conv3d_weights_split")
     return packed
 
 
 @inference_only
 def conv3d_bn_relu_split(x, packed, scale, shift, relu=True, x_absmax=None):
-    """K4 layers with 32 input channels (conv0: 32 -> 8, conv4: 32 -> 32), split-operand form: x (B,D,h,w,32) fp32 ->
-    (B,D,h,w,Cout) fp32 (Cout = len(scale)) on fp16 MFMA with two-term operand
+    """K4's stride-1 layers with 16 or 32 input channels (conv0: 32 -> 8, conv2: 16 -> 16, conv4: 32 -> 32), split-operand
+    form: x (B,D,h,w,Cin) fp32 -> (B,D,h,w,Cout) fp32 (Cout = len(scale)) on fp16 MFMA with two-term operand
     splitting and power-of-two range scaling (mvd_conv3d_bn_relu_f32_split; fp32-grade results for inputs of any
     magnitude).  x_absmax: one-element device tensor with max |x| (warp_variance(..., return_absmax=True)); computed here
     with a streaming pass over x when omitted."""
     lib = L.load()
     x = L.as_f32(x, "x")
-    if x.dim() != 5 or x.shape[-1] != 32:
-        raise ValueError(f"x must be (B,D,h,w,32) channel-last, got {tuple(x.shape)}")
-    B, D, h, w, _ = x.shape
+    if x.dim() != 5 or x.shape[-1] not in (16, 32):
+        raise ValueError(f"x must be (B,D,h,w,16 or 32) channel-last, got {tuple(x.shape)}")
+    B, D, h, w, cin = x.shape
     dev = x.device
     scale = L.as_f32(scale, "scale", device=dev)
     cout = scale.numel()
-    if packed.numel() != lib.mvd_conv3d_split_packed_weight_bytes(32, cout):
-        raise ValueError(f"packed weights of {packed.numel()} bytes do not belong to a 32 -> {cout} layer")
+    if packed.numel() != lib.mvd_conv3d_split_packed_weight_bytes(cin, cout):
+        raise ValueError(f"packed weights of {packed.numel()} bytes do not belong to a {cin} -> {cout} layer")
     shift = L.as_f32(shift, "shift", (cout,), dev)
     y = torch.empty((B, D, h, w, cout), dtype=torch.float32, device=dev)
     if x_absmax is None:
@@ -420,7 +420,7 @@ def conv3d_bn_relu_split(x, packed, scale, shift, relu=True, x_absmax=None):
     x_absmax = L.as_f32(x_absmax, "x_absmax", (1,), dev)
     with torch.cuda.device(dev):
         rc = lib.mvd_conv3d_bn_relu_f32_split(L.ptr(x), L.ptr(x_absmax), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), B, D, h, w,
-                                              32, cout, int(bool(relu)), L.stream_of(x))
+                                              cin, cout, int(bool(relu)), L.stream_of(x))
     L.check(rc, "mvd_conv3d_bn_relu_f32_split")
     return y
 

@@ -182,14 +182,15 @@ def test_conv0_split_error_vs_float64_across_magnitudes(mag, wmag, dev):
     assert err_s <= 1.5 * err_f, (err_s, err_f)
 
 
-@pytest.mark.parametrize("cout,D,h,w", [(32, 8, 12, 40), (16, 5, 7, 50), (64, 4, 9, 33)])
-def test_conv_split_more_output_channels_vs_oracle_and_float64(cout, D, h, w, dev):
+@pytest.mark.parametrize("cin,cout,D,h,w", [(32, 32, 8, 12, 40), (32, 16, 5, 7, 50), (32, 64, 4, 9, 33), (16, 16, 8, 12, 40), (16, 8, 5, 7, 50),
+                                            (16, 32, 9, 6, 64), (16, 16, 3, 5, 31)])
+def test_conv_split_more_output_channels_vs_oracle_and_float64(cin, cout, D, h, w, dev):
     """the split-operand kernel with 16 / 32 / 64 output channels (8 per workgroup; conv4 of the regulariser is 32 -> 32):
     against the C oracle at the block tolerance, and against float64 no worse than 1.5 x the fp32-MFMA kernel"""
     from robustmvd_amd import ops, _lib as L
-    rng = np.random.default_rng(cout + w)
-    x = np.abs(rng.standard_normal((32, D, h, w)) * rng.choice([1e-2, 1.0, 20.0], size=(32, 1, 1, 1))).astype(np.float32)
-    wt = (rng.standard_normal((cout, 32, 3, 3, 3)) * np.sqrt(2 / (32 * 27))).astype(np.float32)
+    rng = np.random.default_rng(cout + w + cin)
+    x = np.abs(rng.standard_normal((cin, D, h, w)) * rng.choice([1e-2, 1.0, 20.0], size=(cin, 1, 1, 1))).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3, 3)) * np.sqrt(2 / (cin * 27))).astype(np.float32)
     scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
     shift = (rng.standard_normal(cout) * 0.1).astype(np.float32)
     xt = T(x, dev).permute(1, 2, 3, 0).contiguous()[None]
@@ -201,7 +202,7 @@ def test_conv_split_more_output_channels_vs_oracle_and_float64(cout, D, h, w, de
     w32, _, _ = ops.pack_conv3d_weights(T(wt, dev), L.CONV3D_STRIDE1)
     one, zero = np.ones(cout, np.float32), np.zeros(cout, np.float32)
     a = ops.conv3d_bn_relu_split(xt, ops.pack_conv3d_weights_split(T(wt, dev)), T(one, dev), T(zero, dev), relu=False)
-    b_ = ops.conv3d_bn_relu(xt, w32, 32, cout, T(one, dev), T(zero, dev), L.CONV3D_STRIDE1, relu=False)
+    b_ = ops.conv3d_bn_relu(xt, w32, cin, cout, T(one, dev), T(zero, dev), L.CONV3D_STRIDE1, relu=False)
     r64 = np.zeros((cout, D, h, w))
     xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (1, 1)))
     for kd in range(3):
