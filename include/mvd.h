@@ -195,6 +195,12 @@ int mvd_pack_conv3d_weights_f32(const float* w, int Cin, int Cout, int mode, flo
 int mvd_conv3d_bn_relu_f32(const float* x, const float* packed_w, const float* scale, const float* shift,
                            const float* skip, float* y, int B, int Di, int hi, int wi, int Cin, int Cout, int mode,
                            int relu, mvd_stream_t stream);
+/* The same, and max |y| over the finite outputs into *absmax_out (device, one float): what mvd_conv3d_bn_relu_f32_split scales
+ * the activations of a following layer by.  A by-product of the store epilogue of the stride-2 layers (the regulariser's conv1
+ * and conv3, whose outputs its split-operand conv2 and conv4 consume); after any other mode a pass over y (mvd_absmax_f32). */
+int mvd_conv3d_bn_relu_absmax_f32(const float* x, const float* packed_w, const float* scale, const float* shift,
+                                  const float* skip, float* y, float* absmax_out, int B, int Di, int hi, int wi, int Cin,
+                                  int Cout, int mode, int relu, mvd_stream_t stream);
 
 /* K4, fp16-input first layer (BASELINE.json configs[3]: "3D-conv regulariser on MFMA, fp16 features"): conv0 of
  * CostRegNet (mvsnet_components.py:78; ConvBnReLU3D 32 -> 8, 3x3x3, stride 1, padding 1, :25-41) on

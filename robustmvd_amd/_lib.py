@@ -61,6 +61,7 @@ SIGNATURES = {
     "mvd_conv3d_packed_weight_floats": (_sz, [_i, _i]),
     "mvd_pack_conv3d_weights_f32": (_i, [_c_float_p, _i, _i, _i, _c_float_p, ctypes.c_void_p]),
     "mvd_conv3d_bn_relu_f32": (_i, [_c_float_p] * 6 + [_i] * 8 + [ctypes.c_void_p]),
+    "mvd_conv3d_bn_relu_absmax_f32": (_i, [_c_float_p] * 7 + [_i] * 8 + [ctypes.c_void_p]),
     "mvd_conv3d_f16_packed_weight_bytes": (_sz, [_i, _i]),
     "mvd_pack_conv3d_weights_f16": (_i, [_c_float_p, _i, _i, ctypes.c_void_p, ctypes.c_void_p]),
     "mvd_conv3d_bn_relu_f16in": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7

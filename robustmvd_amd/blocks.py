@@ -324,14 +324,18 @@ class CostRegNet(nn.Module):
             conv0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True, x_absmax=x_absmax)
         else:
             conv0 = layer("conv0", x)
-        def split_or_fp32(name, t):  # conv2 (16 -> 16), conv4 (32 -> 32): 8 output channels per workgroup; max |x| by a pass over the (small) input
+        def down_then_same(down, same, t):
+            """conv1 -> conv2 (16 -> 16) and conv3 -> conv4 (32 -> 32): the stride-1 layer on the split-operand kernel, scaled by
+            max |x| of its input, which the stride-2 layer before it leaves behind as a by-product of its store epilogue."""
             if not self.conv0_split:
-                return layer(name, t)
-            _, _, _, sc, sh, _ = pk[name]
-            return ops.conv3d_bn_relu_split(t, pk[name + "_split"], sc, sh, relu=True)
+                return layer(same, layer(down, t))
+            w, cin, cout, scale, shift, mode = pk[down]
+            t, amax = ops.conv3d_bn_relu(t, w, cin, cout, scale, shift, mode, relu=True, return_absmax=True)
+            _, _, _, sc, sh, _ = pk[same]
+            return ops.conv3d_bn_relu_split(t, pk[same + "_split"], sc, sh, relu=True, x_absmax=amax)
 
-        conv2 = split_or_fp32("conv2", layer("conv1", conv0))
-        conv4 = split_or_fp32("conv4", layer("conv3", conv2))
+        conv2 = down_then_same("conv1", "conv2", conv0)
+        conv4 = down_then_same("conv3", "conv4", conv2)
         y = layer("conv6", layer("conv5", conv4))
         y = layer("conv7", y, skip=conv4)
         del conv4

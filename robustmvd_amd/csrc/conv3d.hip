@@ -43,6 +43,7 @@ struct ConvParams {
     const float* shift;
     const float* skip;
     float* y;
+    float* absmax;       // optional (device, one float, zeroed by the caller): max |y| over the finite outputs (conv3d_kernel only)
     int B, Di, hi, wi;   // input dims
     int Do, ho, wo;      // output dims
     int Cout;
@@ -294,40 +295,55 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
         }
     const int orow = DECONV ? 2 * (r0 + wave) + ph : r0 + wave;
     const int oz = DECONV ? 2 * zd + pd : zd;
-    if (orow >= p.ho) return;
-    const size_t row_base = (((size_t)b * p.Do + oz) * p.ho + orow) * p.wo;
+    float amax = 0.f;  // max |y| over this lane's finite outputs (p.absmax)
+    if (orow < p.ho) {
+        const size_t row_base = (((size_t)b * p.Do + oz) * p.ho + orow) * p.wo;
 #pragma unroll
-    for (int c = 0; c < NPW; ++c)
+        for (int c = 0; c < NPW; ++c)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int gcol = c0 + m * 16 + vox;
-            const int ocol = DECONV ? 2 * gcol + c : PAIR ? 2 * gcol + (q >> 1) : gcol;
-            if (ocol >= p.wo) continue;
-            const size_t o = (row_base + ocol) * p.Cout;
+            for (int m = 0; m < MT; ++m) {
+                const int gcol = c0 + m * 16 + vox;
+                const int ocol = DECONV ? 2 * gcol + c : PAIR ? 2 * gcol + (q >> 1) : gcol;
+                if (ocol >= p.wo) continue;
+                const size_t o = (row_base + ocol) * p.Cout;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int cb = PAIR ? 4 * (q & 1) : n * 16 + q * 4;  // first of this lane's 4 output channels
-                if (cb >= p.Cout) continue;
-                float r[4];
+                for (int n = 0; n < NT; ++n) {
+                    const int cb = PAIR ? 4 * (q & 1) : n * 16 + q * 4;  // first of this lane's 4 output channels
+                    if (cb >= p.Cout) continue;
+                    float r[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ch = cb + k;
-                    float val = 0.f;
-                    if (ch < p.Cout) {
-                        val = fmaf(acc[c][m][n][k], esc[n][k], esh[n][k]);
-                        if (p.relu) val = fmaxf(val, 0.f);
-                        if (p.skip) val += p.skip[o + ch];
+                    for (int k = 0; k < 4; ++k) {
+                        const int ch = cb + k;
+                        float val = 0.f;
+                        if (ch < p.Cout) {
+                            val = fmaf(acc[c][m][n][k], esc[n][k], esh[n][k]);
+                            if (p.relu) val = fmaxf(val, 0.f);
+                            if (p.skip) val += p.skip[o + ch];
+                        }
+                        r[k] = val;
                     }
-                    r[k] = val;
-                }
-                if (cb + 3 < p.Cout) {
-                    *reinterpret_cast<float4*>(p.y + o + cb) = make_float4(r[0], r[1], r[2], r[3]);
-                } else {
-                    for (int k = 0; k < 4; ++k)
-                        if (cb + k < p.Cout) p.y[o + cb + k] = r[k];
+                    if (p.absmax)
+                        amax = fmaxf(fmaxf(amax, fmaxf(finite_abs_or_zero(r[0]), finite_abs_or_zero(r[1]))),
+                                     fmaxf(finite_abs_or_zero(r[2]), finite_abs_or_zero(r[3])));
+                    if (cb + 3 < p.Cout) {
+                        *reinterpret_cast<float4*>(p.y + o + cb) = make_float4(r[0], r[1], r[2], r[3]);
+                    } else {
+                        for (int k = 0; k < 4; ++k)
+                            if (cb + k < p.Cout) p.y[o + cb + k] = r[k];
+                    }
                 }
             }
+    }
+    if (p.absmax) {  // what the split-operand layer that consumes y scales by: ONE atomic per workgroup (they serialise on the address)
+        __shared__ float wmax[4];
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if (lane == 0) wmax[wave] = amax;
+        __syncthreads();
+        if (tid == 0) {
+            amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.absmax), __float_as_uint(amax));
         }
+    }
 }
 
 // Stride-1 layers (plain and PAIR) in depth-marching form: a workgroup keeps its 4 x TW tile and walks DZ
@@ -1558,9 +1574,24 @@ int mvd_pack_conv3d_weights_f32(const float* w, int Cin, int Cout, int mode, flo
     return mvd::launch_status("pack_conv3d_weights");
 }
 
+static int conv3d_entry(const float* x, const float* packed_w, const float* scale, const float* shift, const float* skip, float* y,
+                        float* absmax_out, int B, int Di, int hi, int wi, int Cin, int Cout, int mode, int relu, mvd_stream_t stream);
+
 int mvd_conv3d_bn_relu_f32(const float* x, const float* packed_w, const float* scale, const float* shift,
                            const float* skip, float* y, int B, int Di, int hi, int wi, int Cin, int Cout, int mode,
                            int relu, mvd_stream_t stream) {
+    return conv3d_entry(x, packed_w, scale, shift, skip, y, nullptr, B, Di, hi, wi, Cin, Cout, mode, relu, stream);
+}
+
+int mvd_conv3d_bn_relu_absmax_f32(const float* x, const float* packed_w, const float* scale, const float* shift,
+                                  const float* skip, float* y, float* absmax_out, int B, int Di, int hi, int wi, int Cin,
+                                  int Cout, int mode, int relu, mvd_stream_t stream) {
+    MVD_REQUIRE(absmax_out, "conv3d_absmax: NULL argument");
+    return conv3d_entry(x, packed_w, scale, shift, skip, y, absmax_out, B, Di, hi, wi, Cin, Cout, mode, relu, stream);
+}
+
+static int conv3d_entry(const float* x, const float* packed_w, const float* scale, const float* shift, const float* skip, float* y,
+                        float* absmax_out, int B, int Di, int hi, int wi, int Cin, int Cout, int mode, int relu, mvd_stream_t stream) {
     MVD_REQUIRE(x && packed_w && scale && shift && y, "conv3d: NULL argument");
     MVD_REQUIRE(B > 0 && Di > 0 && hi > 0 && wi > 0, "conv3d: non-positive dimension");
     MVD_REQUIRE(mvd::cin_ok(Cin) && mvd::cout_ok(Cout), "conv3d: Cin=%d/Cout=%d unsupported", Cin, Cout);
@@ -1579,12 +1610,22 @@ int mvd_conv3d_bn_relu_f32(const float* x, const float* packed_w, const float* s
         return MVD_ERR_INVALID_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
-    switch (Cin) {
-        case 8: return mvd::dispatch_mode<8>(p, mode, st);
-        case 16: return mvd::dispatch_mode<16>(p, mode, st);
-        case 32: return mvd::dispatch_mode<32>(p, mode, st);
-        case 64: return mvd::dispatch_mode<64>(p, mode, st);
+    // max |y|: a by-product of the store epilogue where the layer runs on conv3d_kernel (every stride-2 layer: the regulariser's
+    // conv1 and conv3, whose outputs the split-operand conv2 and conv4 consume), a pass over y after any other kernel
+    const bool fused = absmax_out && mode == MVD_CONV3D_STRIDE2;
+    if (fused) {
+        if (hipMemsetAsync(absmax_out, 0, sizeof(float), st) != hipSuccess) return mvd::launch_status("conv3d_absmax: memset");
+        p.absmax = absmax_out;
     }
-    return MVD_ERR_INVALID_ARG;
+    int rc = MVD_ERR_INVALID_ARG;
+    switch (Cin) {
+        case 8: rc = mvd::dispatch_mode<8>(p, mode, st); break;
+        case 16: rc = mvd::dispatch_mode<16>(p, mode, st); break;
+        case 32: rc = mvd::dispatch_mode<32>(p, mode, st); break;
+        case 64: rc = mvd::dispatch_mode<64>(p, mode, st); break;
+    }
+    if (rc == MVD_OK && absmax_out && !fused)
+        rc = mvd::absmax_launch(y, (long long)B * p.Do * p.ho * p.wo * Cout, absmax_out, st);
+    return rc;
 }
 }

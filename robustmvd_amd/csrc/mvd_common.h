@@ -12,6 +12,12 @@ void set_error(const char* fmt, ...);
 // measurement hook (mvd_arm_kernel_timing): record the armed events around a main-kernel launch
 void timing_begin(hipStream_t st);
 void timing_end(hipStream_t st);
+// max |x| over the finite values of n floats into *absmax (device, one float; zeroed first): warp_variance.hip
+int absmax_launch(const float* x, long long n, float* absmax, hipStream_t st);
+__device__ __forceinline__ float finite_abs_or_zero(float v) {
+    const float a = fabsf(v);
+    return a <= 3.402823466e38f ? a : 0.f;  // false for inf and NaN
+}
 
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();

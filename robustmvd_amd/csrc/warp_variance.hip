@@ -1239,10 +1239,6 @@ static int launch_warp(const WarpParams& p0, int C, hipStream_t st) {
 
 // max |x| over the FINITE values of n floats into *absmax (zeroed first): NaN and inf do not take part, so that one bad voxel
 // does not set the scale of everything else.  A streaming read: 16 bytes per lane, grid-stride.
-__device__ __forceinline__ float finite_abs_or_zero(float v) {
-    const float a = fabsf(v);
-    return a <= 3.402823466e38f ? a : 0.f;  // false for inf and NaN
-}
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
     __shared__ float wmax[4];
     const long long n4 = n / 4, stride = (long long)gridDim.x * 256;

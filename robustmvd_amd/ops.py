@@ -317,8 +317,10 @@ def pack_conv3d_weights(weight, mode):
 
 
 @inference_only
-def conv3d_bn_relu(x, packed, Cin, Cout, scale, shift, mode, relu=True, skip=None):
-    """K4. x (B,D,h,w,Cin) channel-last -> (B,Do,ho,wo,Cout)."""
+def conv3d_bn_relu(x, packed, Cin, Cout, scale, shift, mode, relu=True, skip=None, return_absmax=False):
+    """K4. x (B,D,h,w,Cin) channel-last -> (B,Do,ho,wo,Cout).  return_absmax: also max |y| over the finite outputs (device,
+    one float; what conv3d_bn_relu_split scales a following layer's activations by): a by-product of the store epilogue of
+    the stride-2 layers, a pass over y otherwise."""
     lib = L.load()
     x = L.as_f32(x, "x")
     if x.dim() != 5 or x.shape[-1] != Cin:
@@ -340,6 +342,13 @@ def conv3d_bn_relu(x, packed, Cin, Cout, scale, shift, mode, relu=True, skip=Non
     if skip is not None:
         skip = L.as_f32(skip, "skip", oshape, dev)
     y = torch.empty(oshape, dtype=torch.float32, device=dev)
+    if return_absmax:
+        amax = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.mvd_conv3d_bn_relu_absmax_f32(L.ptr(x), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(skip), L.ptr(y),
+                                                   L.ptr(amax), B, Di, hi, wi, Cin, Cout, mode, int(bool(relu)), L.stream_of(x))
+        L.check(rc, "mvd_conv3d_bn_relu_absmax_f32")
+        return y, amax
     with torch.cuda.device(dev):
         rc = lib.mvd_conv3d_bn_relu_f32(L.ptr(x), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(skip), L.ptr(y), B, Di,
                                         hi, wi, Cin, Cout, mode, int(bool(relu)), L.stream_of(x))

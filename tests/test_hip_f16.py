@@ -301,3 +301,45 @@ def test_fp16_variant_range_is_plain_ieee(dev):
     y = ops.to_f16(x).float().cpu().numpy()
     assert y[0] == 1.0 and y[1] == 65504.0 and np.isinf(y[2]) and np.isinf(y[3]) and y[4] == -np.inf
     assert y[5] == np.float32(np.float16(6e-8)) and y[6] == 0.0 and np.isnan(y[7])
+
+
+def _finite_absmax(t):
+    a = t.abs().flatten()
+    a = a[torch.isfinite(a)]
+    return float(a.max()) if a.numel() else 0.0
+
+
+@pytest.mark.parametrize("mode_name,cin,cout,shape", [("s2", 8, 16, (8, 12, 40)), ("s2", 16, 32, (6, 10, 34)), ("s2", 32, 64, (4, 8, 18)),
+                                                     ("s1", 16, 16, (5, 7, 20)), ("deconv", 16, 8, (3, 5, 9))])
+@pytest.mark.parametrize("poison", [False, True])
+def test_conv3d_absmax_by_product_equals_a_pass_over_the_output(mode_name, cin, cout, shape, poison, dev):
+    """mvd_conv3d_bn_relu_absmax_f32: max |y| over the FINITE outputs, bit-exact (a max, no arithmetic): fused into the store
+    epilogue of the stride-2 kernel, a separate pass after the others; the output itself is the plain entry point's."""
+    from robustmvd_amd import ops, _lib as L
+    mode = {"s1": L.CONV3D_STRIDE1, "s2": L.CONV3D_STRIDE2, "deconv": L.DECONV3D_STRIDE2}[mode_name]
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = (torch.randn(2, *shape, cin, generator=g) * 3).to(dev)
+    if poison:
+        x[0, 1, 2, 3, 0] = float("inf")
+        x[1, 0, 1, 1, 1] = float("nan")
+    wshape = (cin, cout, 3, 3, 3) if mode_name == "deconv" else (cout, cin, 3, 3, 3)
+    wt = (torch.randn(*wshape, generator=g) * 0.1).to(dev)
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.randn(cout, generator=g) * 0.1).to(dev)
+    packed, _, _ = ops.pack_conv3d_weights(wt, mode)
+    for relu in (True, False):
+        want = ops.conv3d_bn_relu(x, packed, cin, cout, sc, sh, mode, relu=relu)
+        got, amax = ops.conv3d_bn_relu(x, packed, cin, cout, sc, sh, mode, relu=relu, return_absmax=True)
+        assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+        assert float(amax) == _finite_absmax(want) > 0
+        assert float(ops.absmax(want)) == _finite_absmax(want)
+
+
+def test_warp_variance_absmax_by_product_equals_a_pass_over_the_volume(dev):
+    from robustmvd_amd import ops
+    from test_hip_shapes import mvs_inputs
+    for (B, h, w, D, V, C, cl) in [(1, 24, 40, 8, 3, 32, True), (2, 19, 33, 5, 2, 32, True), (1, 16, 24, 4, 2, 8, False)]:
+        feats, projs, key_inv, depth = mvs_inputs(B, C, h, w, D, V, seed=h + V)
+        fs = [T(f, dev) for f in feats]
+        vol, amax = ops.warp_variance(fs[0], fs[1:], [T(p, dev) for p in projs], T(key_inv, dev), T(depth, dev), channels_last=cl,
+                                      return_absmax=True)
+        assert float(amax) == _finite_absmax(vol) > 0
