@@ -231,6 +231,32 @@ size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout);
 int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream);
 int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
                                  float* y, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
+/* ---- Path A's 2-D CNN: split-operand implicit-GEMM convolutions ------------------------------------------------------------
+ * Replace torch.nn.functional.conv2d / conv_transpose2d + bias + LeakyReLU (+ torch.cat of the inputs) of the DispNet blocks of
+ * robust_mvd (rmvd/models/blocks/dispnet_encoder.py:6-27, dispnet_context_encoder.py, learned_fusion.py:8-20,
+ * dispnet_costvolume_encoder.py:7-50, dispnet_decoder.py:36-138).  fp32 in, fp32 out; inside, both operands are split into two
+ * fp16 terms (block-scaled by exact powers of two) and multiplied on fp16 MFMA with fp32 accumulation: fp32-grade results
+ * (csrc/conv2d_split.hip states the bound).
+ * Activations are NHWC with a free pixel stride: x points at the first channel of a slice of Cin_pad channels (a multiple of 8;
+ * channels Cin .. Cin_pad-1 must hold zeros) inside pixels `x_pixel_stride` floats apart, y likewise for Cout channels, so that
+ * layers read and write slices of the decoder's concat buffers directly.  x, y 16-byte aligned, strides multiples of 4.
+ * mode MVD_CONV2D: Conv2d, padding k/2: 1x1 (Cin_pad % 32 == 0), 3x3 stride 1, 3x3 stride 2, 5x5 stride 2; weights (Cout,Cin,k,k).
+ * mode MVD_DECONV2D: ConvTranspose2d 4x4, stride 2, padding 1 (Cin_pad % 32 == 0); weights (Cin,Cout,4,4); output 2Hi x 2Wi.
+ * mode MVD_CONV2D_IMAGE: Conv2d 7x7 stride 2 padding 3 on a PLANAR (B,3,Hi,Wi) image (Cin = 3, Cin_pad = 8, stride argument unused).
+ * x_absmax: device float, max |x| over the input tensor (an upper bound is safe); y_absmax: NULL, or a device float that
+ * receives max |y| by atomic maximum (the caller zeroes it; several layers may share one to cover a concat buffer).
+ * act: 0 none, 1 LeakyReLU(slope), 2 ReLU; bias NULL or (Cout).  workspace: NULL, or mvd_conv2d_split_workspace_bytes bytes:
+ * lets layers with few pixels and many weights split the reduction over workgroups (partial sums added in a fixed order). */
+#define MVD_CONV2D 0
+#define MVD_DECONV2D 1
+#define MVD_CONV2D_IMAGE 2
+size_t mvd_conv2d_split_packed_weight_bytes(int Cin_pad, int Cout, int KH, int KW, int stride, int mode);
+int mvd_pack_conv2d_weights_split(const float* w, int Cin, int Cin_pad, int Cout, int KH, int KW, int stride, int mode, void* packed,
+                                  mvd_stream_t stream);
+size_t mvd_conv2d_split_workspace_bytes(int B, int Hi, int Wi, int Cin_pad, int Cout, int KH, int KW, int stride, int mode);
+int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* packed_w, const float* bias, float* y, float* y_absmax, int B,
+                         int Hi, int Wi, int Cin_pad, int x_pixel_stride, int Cout, int y_pixel_stride, int KH, int KW, int stride, int mode,
+                         int act, float slope, void* workspace, size_t workspace_bytes, mvd_stream_t stream);
 /* max |x[i]| over the FINITE values of n floats (inf and NaN left out, 0 if there is none) into *absmax (device, one
  * float); a streaming read */
 int mvd_absmax_f32(const float* x, long long n, float* absmax, mvd_stream_t stream);

@@ -20,6 +20,7 @@ LAYOUT_NDHWC = 1
 GRID_EXACT = 0x100
 FEAT_NHWC_BORDER = 0x200
 CONV3D_STRIDE1 = 0
+CONV2D, DECONV2D, CONV2D_IMAGE = 0, 1, 2  # mvd_conv2d_split_f32 modes
 CONV3D_STRIDE2 = 1
 DECONV3D_STRIDE2 = 2
 LAYOUT_NCHW = 0
@@ -67,6 +68,11 @@ SIGNATURES = {
     "mvd_conv3d_bn_relu_f16in": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7
                                  + [ctypes.c_void_p]),
     "mvd_conv3d_split_packed_weight_bytes": (_sz, [_i, _i]),
+    "mvd_conv2d_split_packed_weight_bytes": (_sz, [_i] * 6),
+    "mvd_pack_conv2d_weights_split": (_i, [_c_float_p] + [_i] * 7 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "mvd_conv2d_split_workspace_bytes": (_sz, [_i] * 9),
+    "mvd_conv2d_split_f32": (_i, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 12
+                             + [ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "mvd_pack_conv3d_weights_split": (_i, [_c_float_p, _i, _i, ctypes.c_void_p, ctypes.c_void_p]),
     "mvd_conv3d_bn_relu_f32_split": (_i, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7
                                      + [ctypes.c_void_p]),

@@ -1,0 +1,560 @@
+// Path A's 2-D CNN (the DispNet encoder / context encoder / fusion score convs / cost-volume encoder / decoder of robust_mvd:
+// rmvd/models/blocks/dispnet_encoder.py:6-27, dispnet_context_encoder.py, learned_fusion.py:8-20,
+// dispnet_costvolume_encoder.py:7-50, dispnet_decoder.py:36-138) as ONE implicit-GEMM kernel family on fp16 MFMA with
+// split fp32 operands: fp32-grade results at several times the fp32 matrix rate, no layout transposes, no im2col, no `cat`.
+//
+// Arithmetic (the 2-D form of conv3d_split.hip): every fp32 activation a and weight w becomes two fp16 terms,
+//     a 2^-e = a_hi + a_lo,  a_hi = fp16(a 2^-e),  a_lo = fp16(a 2^-e - a_hi)            (same for w with 2^-k_c per cout)
+// and a w is evaluated as a_hi w_hi + a_hi w_lo + a_lo w_hi on v_mfma_f32_16x16x32_f16 with ONE fp32 accumulator (the lo terms
+// are not rescaled here: with the block scaling below they stay in fp16's range, denormals included).  e puts max |x| of the
+// whole input tensor into [2^14, 2^15), k_c puts max |w_c| into [2^10, 2^11); the epilogue multiplies by 2^(e + k_c).  A value v
+// is represented to |error| <= max(2^-22 |v|, 2^-39 max|x|).  max |x| comes from the producer's epilogue (every kernel here can
+// leave max |y| behind: one atomicMax per workgroup) or from mvd_absmax_f32.
+//
+// Data layout: activations NHWC fp32 with a free pixel stride (so that a layer can read or write a channel slice of a wider
+// buffer: the decoder's concat inputs are never copied together), channel count a multiple of 8 (pad channels hold zeros and
+// meet zero weights).  Weights pre-split and pre-packed in MFMA fragment order.
+//
+// GEMM view: D[cout][pixel] += W[cout][k] X[k][pixel], k = (tap, channel).  A workgroup (4 waves) owns a 16 x 16 tile of output
+// pixels and BN output channels.  Per chunk of CC = 8 U8 input channels the input patch the tile needs is staged ONCE in LDS
+// (converted to the two fp16 terms on the way; zero outside the image = the padding), stride-2 layers de-interleave the
+// columns by parity so that the 16 pixels of a fragment read conflict-free.  A K step = 4 units of 8 channels (unit = (tap,
+// 8-channel group)): per step a wave reads 2 activation fragments per pixel row from LDS and its weight fragments straight from
+// L2 (each wave owns its own output channels, so no weight byte is loaded twice per workgroup), 3 MFMAs per 16 x 16 block.
+// Layers with few pixels and many weights (conv5 .. deconv_2) split K over workgroups; partial sums go to a workspace and a
+// second kernel adds them in a fixed order (run-to-run identical) and applies the epilogue.
+//
+// Transposed convolutions (4 x 4, stride 2, padding 1) run as four 2 x 2 stride-1 layers, one per output parity class.
+#include "mvd_common.h"
+
+namespace mvd {
+
+typedef _Float16 c2h8 __attribute__((ext_vector_type(8)));
+typedef float c2f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int c2u4 __attribute__((ext_vector_type(4)));
+
+constexpr int C2_TH = 16, C2_TW = 16;  // output pixels per workgroup tile
+
+template <int KH, int KW, int S, int U8>
+struct C2Geom {
+    static constexpr int CC = 8 * U8;                          // input channels per staged chunk
+    static constexpr int PB = CC * 2 + (U8 % 2 == 0 ? 16 : 0); // LDS bytes per pixel and term: PB / 16 odd = conflict-free rows
+    static constexpr int PH = (C2_TH - 1) * S + KH, PW = (C2_TW - 1) * S + KW;  // staged patch
+    static constexpr int PWS = (PW + S - 1) / S;               // columns per parity plane
+    static constexpr int ROWB = S * S * PWS * PB;              // LDS bytes between the patch rows of consecutive OUTPUT rows
+    static constexpr int PLANE = PH * S * PWS * PB;            // one term of the patch
+    static constexpr int UNITS = KH * KW * U8;                 // (tap, 8-channel group) units per chunk
+    static constexpr int STEPS = (UNITS + 3) / 4;              // MFMA K steps (32 = 4 units) per chunk
+    static constexpr int ITEMS = PH * PW * U8;                 // staging items (pixel, 8-channel group)
+    static constexpr int NIT = (ITEMS + 255) / 256;
+    static_assert(2 * PLANE <= 80 * 1024, "patch exceeds half the LDS (two workgroups per CU)");
+    static_assert((PB / 16) % 2 == 1, "pixel pitch must be an odd number of 16-byte slots");
+};
+
+struct C2Params {
+    const float* x;       // input, NHWC, first channel of the slice; pixel stride xs floats.  NCHW3: (B, 3, Hi, Wi) planes
+    const float* xamax;   // max |x| (device, one float)
+    const char* wpk;      // packed weight fragments (transposed conv: 4 parity classes, cls_bytes apart)
+    const float* eun;     // per output channel 2^k_c (padded to a multiple of 16)
+    const float* bias;    // Cout or NULL
+    float* y;             // output, NHWC, first channel of the slice; pixel stride ys floats
+    float* yamax;         // optional: max |y| over the finite outputs (atomicMax; zeroed by the caller)
+    float* part;          // split-K: partial sums [ksplit][B Ho Wo][ncp]; NULL = direct epilogue
+    int B, Hi, Wi, xs, nchunks;
+    int Ho, Wo;           // output grid of this launch (transposed conv: one parity class = the input grid)
+    int Hy, Wy, ys;       // the output tensor's full grid
+    int oy_mul, ox_mul;   // output pixel (oy, ox) of the grid lands at (oy * oy_mul + a, ox * ox_mul + b)
+    int pad_y, pad_x;     // input row of tap ky for output row oy: oy * S - pad_y + ky
+    int Cout, ncp;        // output channels; ncp = Cout padded to the launch's BN
+    int tiles_x, tiles_y, nblocks, ksplit, chunks_per_split;
+    int ncls;             // 1, or 4 = the output parity classes (a, b) of a transposed conv: pad - (a, b), output offset (a, b)
+    long long cls_bytes;
+    int act;              // 0 none, 1 LeakyReLU(slope), 2 ReLU
+    float slope;
+};
+
+// per output channel 2^k_c, k_c = exponent(max |w_c|) - 10 (0 for an all-zero channel); Conv2d (Cout, Cin, KH, KW) or
+// ConvTranspose2d (Cin, Cout, KH, KW) layout
+__global__ void c2_wscale_kernel(const float* __restrict__ w, float* __restrict__ eun, int Cin, int Cout, int taps, int transposed, int cpad) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float m = 0.f;
+    if (c < Cout)
+        for (int e = threadIdx.x; e < Cin * taps; e += 256) {
+            const int ci = e / taps, t = e % taps;
+            const float v = fabsf(transposed ? w[((size_t)ci * Cout + c) * taps + t] : w[((size_t)c * Cin + ci) * taps + t]);
+            m = (v <= 3.4e38f && v > m) ? v : m;
+        }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && c < cpad) {
+        const int ex = (int)((__float_as_uint(red[0]) >> 23) & 0xffu) - 127;
+        const int k = red[0] > 0.f ? max(-100, min(100, ex - 10)) : 0;
+        eun[c] = ldexpf(1.0f, k);
+    }
+}
+
+// -> [class][cout tile (16)][chunk][step][term hi, lo][lane 64][8 halves]; lane l: cout 16 nt + l % 16, unit 4 step + l / 16,
+// unit u = (tap u / U8, 8-channel group u % U8), channel = chunk CC + 8 (u % U8) + j.  Units past the taps, channels past Cin
+// and output channels past Cout get zeros.  Transposed (4 x 4, stride 2, padding 1) class (a, b): tap (ty, tx) of the 2 x 2
+// layer = kernel element (3 - a - 2 ty, 3 - b - 2 tx).
+__global__ void c2_pack_kernel(const float* __restrict__ w, const float* __restrict__ eun, _Float16* __restrict__ packed, int Cin, int Cout,
+                               int KH, int KW, int U8, int nchunks, int ntiles, int steps, int transposed, long long total) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), term = (int)((e >> 9) & 1);
+    long long r = e >> 10;
+    const int step = (int)(r % steps); r /= steps;
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int nt = (int)(r % ntiles);
+    const int cls = (int)(r / ntiles);
+    const int cout = nt * 16 + (lane & 15), unit = 4 * step + (lane >> 4);
+    const int tap = unit / U8, cin = chunk * 8 * U8 + 8 * (unit % U8) + j;
+    float v = 0.f;
+    if (tap < KH * KW && cin < Cin && cout < Cout) {
+        const int ty = tap / KW, tx = tap % KW;
+        if (transposed) {
+            const int a = cls >> 1, b = cls & 1, ky = 3 - a - 2 * ty, kx = 3 - b - 2 * tx;
+            v = w[(((size_t)cin * Cout + cout) * 4 + ky) * 4 + kx];
+        } else {
+            v = w[(((size_t)cout * Cin + cin) * KH + ty) * KW + tx];
+        }
+        v = v / eun[cout];
+    }
+    const _Float16 hi = (_Float16)v;
+    packed[e] = term == 0 ? hi : (_Float16)(v - (float)hi);
+}
+
+template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
+__global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
+    using G = C2Geom<KH, KW, S, U8>;
+    constexpr int WN = 4 / WM, MTW = 16 / WM, STEPS = G::STEPS, PB = G::PB, PLANE = G::PLANE;
+    extern __shared__ __attribute__((aligned(16))) char patch[];  // [term][row][column parity][column / S][PB]
+    __shared__ float wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int g = lane >> 4, px16 = lane & 15;
+
+    int bx = blockIdx.x;
+    const int nb = bx % p.nblocks; bx /= p.nblocks;
+    const int ks = bx % p.ksplit; bx /= p.ksplit;
+    const int cls = bx % p.ncls; bx /= p.ncls;
+    const int tx = bx % p.tiles_x; bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int ca = cls >> 1, cb2 = cls & 1;  // (0, 0) for a plain convolution
+    const int oy0 = ty * C2_TH, ox0 = tx * C2_TW;
+    const int iy0 = oy0 * S - (p.pad_y - ca), ix0 = ox0 * S - (p.pad_x - cb2);
+
+    // activation scale 2^-e, e = exponent(max |x|) - 14
+    float xsc, xsc_inv;
+    {
+        const unsigned mb = __builtin_amdgcn_readfirstlane((int)__float_as_uint(*p.xamax));
+        const int ex = (int)((mb >> 23) & 0xffu) - 127;
+        const int e = max(-125, min(125, ex - 14));
+        xsc = __uint_as_float((unsigned)(127 - e) << 23);
+        xsc_inv = __uint_as_float((unsigned)(127 + e) << 23);
+    }
+    const float one = 1.0f;
+    auto split2 = [xsc, one](float a0, float a1, unsigned& hi, unsigned& lo) {
+        unsigned hp, lp;
+        float t0, t1;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(hp) : "v"(a0), "s"(xsc));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(hp) : "v"(a1), "s"(xsc));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(t0) : "v"(a0), "s"(xsc), "v"(hp));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(t1) : "v"(a1), "s"(xsc), "v"(hp));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(lp) : "v"(t0), "s"(one));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lp) : "v"(t1), "s"(one));
+        hi = hp;
+        lo = lp;
+    };
+
+    // staging items of this thread: global offset (floats, without the chunk's channel offset; -1 = outside the image) and LDS byte
+    long long goff[G::NIT];
+    int loff[G::NIT];
+#pragma unroll
+    for (int k = 0; k < G::NIT; ++k) {
+        const int it = tid + 256 * k;
+        const int pix = it / U8, c8 = it % U8;
+        const int py = pix / G::PW, pxx = pix % G::PW;
+        const int iy = iy0 + py, ix = ix0 + pxx;
+        const bool live = it < G::ITEMS;
+        const bool inside = live && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        if constexpr (NCHW3) goff[k] = inside ? ((long long)b * 3 * p.Hi + iy) * p.Wi + ix : -1;
+        else goff[k] = inside ? (((long long)b * p.Hi + iy) * p.Wi + ix) * p.xs + c8 * 8 : -1;
+        loff[k] = live ? ((py * S + pxx % S) * G::PWS + pxx / S) * PB + c8 * 16 : -1;
+    }
+
+    // activation fragment address of this lane per K step (row 0 of the wave's rows)
+    int tapoff[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        int unit = 4 * s + g;
+        if (unit >= G::UNITS) unit = 0;  // meets zero weights
+        const int tap = unit / U8, c8 = unit % U8, ky = tap / KW, kx = tap % KW;
+        tapoff[s] = ((ky * S + kx % S) * G::PWS + kx / S + px16) * PB + c8 * 16 + wm * MTW * G::ROWB;
+    }
+
+    // weights: this wave's cout tiles
+    const int nt0 = nb * (WN * NTW) + wn * NTW;
+    const size_t nt_stride = (size_t)p.nchunks * STEPS * 2048;
+    const char* wlane = p.wpk + (size_t)cls * p.cls_bytes + (size_t)nt0 * nt_stride + lane * 16;
+
+    c2f4 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[m][t] = c2f4{0, 0, 0, 0};
+
+    const int c_begin = ks * p.chunks_per_split, c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+
+    // weight fragments one K step ahead (steps and chunks are consecutive in the packed buffer); the last prefetch re-reads
+    c2h8 wh[NTW], wl[NTW];
+    const char* wc = wlane + (size_t)c_begin * STEPS * 2048;
+    const char* const wlast = wlane + ((size_t)max(c_end, c_begin + 1) * STEPS - 1) * 2048;
+    if (c_begin < c_end) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            wh[t] = *reinterpret_cast<const c2h8*>(wc + t * nt_stride);
+            wl[t] = *reinterpret_cast<const c2h8*>(wc + t * nt_stride + 1024);
+        }
+    }
+
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        // ---- stage the chunk's patch: global fp32 -> two fp16 terms -> LDS -------------------------------------------------------
+        {
+            c2f4 v0[G::NIT], v1[G::NIT];
+#pragma unroll
+            for (int k = 0; k < G::NIT; ++k) {
+                v0[k] = c2f4{0, 0, 0, 0};
+                v1[k] = c2f4{0, 0, 0, 0};
+                if (goff[k] >= 0) {
+                    if constexpr (NCHW3) {
+                        const size_t pl = (size_t)p.Hi * p.Wi;
+                        v0[k][0] = p.x[goff[k]]; v0[k][1] = p.x[goff[k] + pl]; v0[k][2] = p.x[goff[k] + 2 * pl];
+                    } else {
+                        const float* src = p.x + goff[k] + (size_t)chunk * G::CC;
+                        v0[k] = *reinterpret_cast<const c2f4*>(src);
+                        v1[k] = *reinterpret_cast<const c2f4*>(src + 4);
+                    }
+                }
+            }
+            __syncthreads();  // every wave has finished reading the previous chunk's patch
+#pragma unroll
+            for (int k = 0; k < G::NIT; ++k) {
+                if (loff[k] < 0) continue;
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                split2(v0[k][0], v0[k][1], h0, l0);
+                split2(v0[k][2], v0[k][3], h1, l1);
+                split2(v1[k][0], v1[k][1], h2, l2);
+                split2(v1[k][2], v1[k][3], h3, l3);
+                *reinterpret_cast<c2u4*>(patch + loff[k]) = c2u4{h0, h1, h2, h3};
+                *reinterpret_cast<c2u4*>(patch + loff[k] + PLANE) = c2u4{l0, l1, l2, l3};
+            }
+            __syncthreads();
+        }
+
+        // ---- K steps: activation fragments one pixel row ahead, weights one step ahead ---------------------------------------------
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            c2h8 nh[NTW], nl[NTW];
+            {
+                const char* wn = wc + 2048;
+                wn = wn > wlast ? wlast : wn;
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    nh[t] = *reinterpret_cast<const c2h8*>(wn + t * nt_stride);
+                    nl[t] = *reinterpret_cast<const c2h8*>(wn + t * nt_stride + 1024);
+                }
+                wc += 2048;
+            }
+            const char* a = patch + tapoff[s];
+            c2h8 xh = *reinterpret_cast<const c2h8*>(a), xl = *reinterpret_cast<const c2h8*>(a + PLANE);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const c2h8 ch = xh, cl = xl;
+                if (m + 1 < MTW) {
+                    xh = *reinterpret_cast<const c2h8*>(a + (m + 1) * G::ROWB);
+                    xl = *reinterpret_cast<const c2h8*>(a + (m + 1) * G::ROWB + PLANE);
+                }
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], ch, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], ch, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], cl, acc[m][t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keeps the compiler from hoisting every row's reads to the top (registers)
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) { wh[t] = nh[t]; wl[t] = nl[t]; }
+        }
+    }
+
+    // ---- epilogue: lane holds output channels cb .. cb + 3 of pixel (row m, column px16) -------------------------------------------
+    const int ox = ox0 + px16;
+    float amax = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int cb = (nt0 + t) * 16 + 4 * g;
+        if (p.part) {  // split K: raw partial sums, the reduce kernel applies the epilogue
+            if (ox < p.Wo)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int oy = oy0 + wm * MTW + m;
+                    if (oy >= p.Ho) continue;
+                    const size_t pl = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+                    *reinterpret_cast<c2f4*>(p.part + (((size_t)cls * p.ksplit + ks) * p.B * p.Ho * p.Wo + pl) * p.ncp + cb) = acc[m][t];
+                }
+            continue;
+        }
+        if (cb >= p.Cout) continue;
+        const c2f4 eu = *reinterpret_cast<const c2f4*>(p.eun + cb);
+        float bs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[r] = (p.bias && cb + r < p.Cout) ? p.bias[cb + r] : 0.f;
+        if (ox < p.Wo)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int oy = oy0 + wm * MTW + m;
+                if (oy >= p.Ho) continue;
+                float* dst = p.y + (((size_t)b * p.Hy + (size_t)oy * p.oy_mul + ca) * p.Wy + (size_t)ox * p.ox_mul + cb2) * p.ys + cb;
+                float r4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaf(acc[m][t][r], eu[r] * xsc_inv, bs[r]);
+                    if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+                    else if (p.act == 2) v = fmaxf(v, 0.f);
+                    r4[r] = v;
+                    if (cb + r < p.Cout) amax = fmaxf(amax, finite_abs_or_zero(v));
+                }
+                if (cb + 3 < p.Cout) {
+                    *reinterpret_cast<c2f4*>(dst) = c2f4{r4[0], r4[1], r4[2], r4[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (cb + r < p.Cout) dst[r] = r4[r];
+                }
+            }
+    }
+    if (p.yamax && !p.part) {
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if (lane == 0) wmax[wv] = amax;
+        __syncthreads();
+        if (tid == 0) {
+            amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.yamax), __float_as_uint(amax));
+        }
+    }
+}
+
+// split K, second kernel: partial sums added in the fixed order ks = 0, 1, ...; then the same epilogue.  One thread = 4 channels.
+__global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
+    __shared__ float wmax[4];
+    const long long npix = (long long)p.B * p.Ho * p.Wo;
+    const int c4n = (p.Cout + 3) / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float amax = 0.f;
+    if (i < npix * c4n * p.ncls) {
+        const int cls = (int)(i / (npix * c4n));
+        const long long pl = (i / c4n) % npix;
+        const int cb = (int)(i % c4n) * 4;
+        c2f4 s = c2f4{0, 0, 0, 0};
+        for (int ks = 0; ks < p.ksplit; ++ks)
+            s += *reinterpret_cast<const c2f4*>(p.part + (((size_t)cls * p.ksplit + ks) * npix + pl) * p.ncp + cb);
+        float xsc_inv;
+        {
+            const unsigned mb = __float_as_uint(*p.xamax);
+            const int ex = (int)((mb >> 23) & 0xffu) - 127;
+            const int e = max(-125, min(125, ex - 14));
+            xsc_inv = __uint_as_float((unsigned)(127 + e) << 23);
+        }
+        const int ox = (int)(pl % p.Wo), oy = (int)((pl / p.Wo) % p.Ho), b = (int)(pl / ((long long)p.Wo * p.Ho));
+        float* dst = p.y + (((size_t)b * p.Hy + (size_t)oy * p.oy_mul + (cls >> 1)) * p.Wy + (size_t)ox * p.ox_mul + (cls & 1)) * p.ys + cb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (cb + r >= p.Cout) break;
+            float v = fmaf(s[r], p.eun[cb + r] * xsc_inv, p.bias ? p.bias[cb + r] : 0.f);
+            if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+            else if (p.act == 2) v = fmaxf(v, 0.f);
+            dst[r] = v;
+            amax = fmaxf(amax, finite_abs_or_zero(v));
+        }
+    }
+    if (p.yamax) {
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.yamax), __float_as_uint(amax));
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+struct C2Shape {
+    int KH, KW, S, U8, steps;
+    bool transposed, nchw3;
+};
+
+// the layer kinds that are built.  mode 0: Conv2d, 1: ConvTranspose2d 4 x 4 stride 2 padding 1, 2: Conv2d on a (B, 3, H, W) image
+static bool c2_shape(int KH, int KW, int stride, int mode, int cin_pad, C2Shape* s) {
+    s->transposed = mode == 1;
+    s->nchw3 = mode == 2;
+    s->KH = KH; s->KW = KW; s->S = stride;
+    if (mode == 1) {
+        if (KH != 4 || KW != 4 || stride != 2 || cin_pad % 32) return false;
+        s->KH = s->KW = 2; s->S = 1; s->U8 = 4;
+    } else if (mode == 2) {
+        if (KH != 7 || KW != 7 || stride != 2 || cin_pad != 8) return false;
+        s->U8 = 1;
+    } else if (KH == 1 && KW == 1 && stride == 1) {
+        if (cin_pad % 32) return false;
+        s->U8 = 4;
+    } else if (KH == 3 && KW == 3 && stride == 1) {
+        s->U8 = cin_pad % 32 == 0 ? 4 : 1;
+    } else if ((KH == 3 && KW == 3 && stride == 2) || (KH == 5 && KW == 5 && stride == 2)) {
+        s->U8 = 1;
+    } else {
+        return false;
+    }
+    if (cin_pad % (8 * s->U8)) return false;
+    s->steps = (s->KH * s->KW * s->U8 + 3) / 4;
+    return true;
+}
+
+// output channels per workgroup: the widest tile that does not leave most of it empty
+static int c2_bn(int cout) { return cout > 64 ? 128 : cout > 32 ? 64 : cout > 16 ? 32 : 16; }
+static int c2_ntiles(int cout) { return (cout + c2_bn(cout) - 1) / c2_bn(cout) * (c2_bn(cout) / 16); }  // 16-channel tiles, whole workgroups
+static size_t c2_frag_bytes(const C2Shape& s, int cin_pad, int cout) {
+    const size_t nchunks = (size_t)cin_pad / (8 * s.U8);
+    return (s.transposed ? 4 : 1) * (size_t)c2_ntiles(cout) * nchunks * s.steps * 2048;
+}
+static int c2_cpad(int cout) { return (cout + 127) / 128 * 128; }  // eun entries: any BN reads whole float4s
+
+template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
+static int c2_launch(const C2Params& p, long long nblk, hipStream_t st) {
+    using G = C2Geom<KH, KW, S, U8>;
+    auto kern = conv2d_split_kernel<KH, KW, S, U8, WM, NTW, NCHW3>;
+    constexpr int lds = 2 * G::PLANE;
+    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return launch_status("conv2d_split: LDS attribute");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    return launch_status("conv2d_split");
+}
+
+// tile of output channels per workgroup: bn = 16 WN NTW
+template <int KH, int KW, int S, int U8, bool NCHW3>
+static int c2_launch_bn(const C2Params& p, int bn, long long nblk, hipStream_t st) {
+    switch (bn) {
+        case 128: return c2_launch<KH, KW, S, U8, 1, 2, NCHW3>(p, nblk, st);
+        case 64: return c2_launch<KH, KW, S, U8, 1, 1, NCHW3>(p, nblk, st);
+        case 32: return c2_launch<KH, KW, S, U8, 2, 1, NCHW3>(p, nblk, st);
+        case 16: return c2_launch<KH, KW, S, U8, 4, 1, NCHW3>(p, nblk, st);
+    }
+    return MVD_ERR_INVALID_ARG;
+}
+
+static int c2_dispatch(const C2Shape& s, const C2Params& p, int bn, long long nblk, hipStream_t st) {
+    if (s.nchw3) return c2_launch_bn<7, 7, 2, 1, true>(p, bn, nblk, st);
+    if (s.KH == 1) return c2_launch_bn<1, 1, 1, 4, false>(p, bn, nblk, st);
+    if (s.KH == 2) return c2_launch_bn<2, 2, 1, 4, false>(p, bn, nblk, st);
+    if (s.KH == 5) return c2_launch_bn<5, 5, 2, 1, false>(p, bn, nblk, st);
+    if (s.S == 2) return c2_launch_bn<3, 3, 2, 1, false>(p, bn, nblk, st);
+    if (s.U8 == 4) return c2_launch_bn<3, 3, 1, 4, false>(p, bn, nblk, st);
+    return c2_launch_bn<3, 3, 1, 1, false>(p, bn, nblk, st);
+}
+
+}  // namespace mvd
+
+extern "C" {
+
+size_t mvd_conv2d_split_packed_weight_bytes(int Cin_pad, int Cout, int KH, int KW, int stride, int mode) {
+    mvd::C2Shape s;
+    if (Cin_pad <= 0 || Cout <= 0 || !mvd::c2_shape(KH, KW, stride, mode, Cin_pad, &s)) return 0;
+    return mvd::c2_frag_bytes(s, Cin_pad, Cout) + (size_t)mvd::c2_cpad(Cout) * sizeof(float);
+}
+
+int mvd_pack_conv2d_weights_split(const float* w, int Cin, int Cin_pad, int Cout, int KH, int KW, int stride, int mode, void* packed,
+                                  mvd_stream_t stream) {
+    MVD_REQUIRE(w && packed, "pack_conv2d_weights_split: NULL argument");
+    mvd::C2Shape s;
+    MVD_REQUIRE(Cin > 0 && Cin <= Cin_pad && Cout > 0 && mvd::c2_shape(KH, KW, stride, mode, Cin_pad, &s),
+                "pack_conv2d_weights_split: layer %dx%d stride %d mode %d with %d (padded %d) -> %d channels is not built", KH, KW, stride, mode,
+                Cin, Cin_pad, Cout);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t fb = mvd::c2_frag_bytes(s, Cin_pad, Cout);
+    float* eun = reinterpret_cast<float*>(static_cast<char*>(packed) + fb);
+    const int cpad = mvd::c2_cpad(Cout);
+    hipLaunchKernelGGL(mvd::c2_wscale_kernel, dim3(cpad), dim3(256), 0, st, w, eun, Cin, Cout, KH * KW, s.transposed ? 1 : 0, cpad);
+    const long long total = (long long)(fb / 2);
+    hipLaunchKernelGGL(mvd::c2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, eun, (_Float16*)packed, Cin, Cout, s.KH,
+                       s.KW, s.U8, Cin_pad / (8 * s.U8), mvd::c2_ntiles(Cout), s.steps, s.transposed ? 1 : 0, total);
+    return mvd::launch_status("pack_conv2d_weights_split");
+}
+
+size_t mvd_conv2d_split_workspace_bytes(int B, int Hi, int Wi, int Cin_pad, int Cout, int KH, int KW, int stride, int mode) {
+    // upper bound over the split the launcher may choose: 32 partial sums per output
+    mvd::C2Shape s;
+    if (!mvd::c2_shape(KH, KW, stride, mode, Cin_pad, &s)) return 0;
+    const long long Ho = mode == 1 ? Hi : (Hi + 2 * (KH / 2) - KH) / stride + 1, Wo = mode == 1 ? Wi : (Wi + 2 * (KW / 2) - KW) / stride + 1;
+    return (size_t)32 * (mode == 1 ? 4 : 1) * B * Ho * Wo * mvd::c2_cpad(Cout) * sizeof(float);
+}
+
+int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* packed_w, const float* bias, float* y, float* y_absmax, int B,
+                         int Hi, int Wi, int Cin_pad, int x_pixel_stride, int Cout, int y_pixel_stride, int KH, int KW, int stride, int mode,
+                         int act, float slope, void* workspace, size_t workspace_bytes, mvd_stream_t stream) {
+    MVD_REQUIRE(x && x_absmax && packed_w && y, "conv2d_split: NULL argument");
+    MVD_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "conv2d_split: non-positive dimension");
+    mvd::C2Shape s;
+    MVD_REQUIRE(Cin_pad > 0 && Cout > 0 && mvd::c2_shape(KH, KW, stride, mode, Cin_pad, &s),
+                "conv2d_split: layer %dx%d stride %d mode %d with %d -> %d channels is not built", KH, KW, stride, mode, Cin_pad, Cout);
+    MVD_REQUIRE(mode == 2 || (x_pixel_stride >= Cin_pad && x_pixel_stride % 4 == 0), "conv2d_split: input pixel stride %d (channels %d)",
+                x_pixel_stride, Cin_pad);
+    MVD_REQUIRE(y_pixel_stride >= Cout, "conv2d_split: output pixel stride %d below %d channels", y_pixel_stride, Cout);
+    MVD_REQUIRE(act >= 0 && act <= 2, "conv2d_split: act=%d unknown", act);
+    MVD_REQUIRE(mode == 2 || (((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0), "conv2d_split: x and y must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    mvd::C2Params p{};
+    p.x = x; p.xamax = x_absmax; p.bias = bias; p.y = y; p.yamax = y_absmax;
+    p.B = B; p.Hi = Hi; p.Wi = Wi; p.xs = x_pixel_stride; p.nchunks = Cin_pad / (8 * s.U8);
+    p.Cout = Cout; p.ys = y_pixel_stride; p.act = act; p.slope = slope;
+    const size_t fb = mvd::c2_frag_bytes(s, Cin_pad, Cout);
+    p.eun = reinterpret_cast<const float*>(static_cast<const char*>(packed_w) + fb);
+    if (s.transposed) {
+        p.Ho = Hi; p.Wo = Wi; p.Hy = 2 * Hi; p.Wy = 2 * Wi; p.oy_mul = p.ox_mul = 2; p.pad_y = p.pad_x = 1; p.ncls = 4;
+    } else {
+        const int ph = KH / 2, pw = KW / 2;
+        p.Ho = (Hi + 2 * ph - KH) / stride + 1; p.Wo = (Wi + 2 * pw - KW) / stride + 1;
+        p.Hy = p.Ho; p.Wy = p.Wo; p.oy_mul = p.ox_mul = 1; p.pad_y = ph; p.pad_x = pw; p.ncls = 1;
+    }
+    MVD_REQUIRE((y_pixel_stride % 4 == 0) || Cout < 4, "conv2d_split: output pixel stride %d must be a multiple of 4", y_pixel_stride);
+    p.wpk = static_cast<const char*>(packed_w);
+    p.cls_bytes = (long long)(fb / p.ncls);
+    p.tiles_y = (p.Ho + mvd::C2_TH - 1) / mvd::C2_TH;
+    p.tiles_x = (p.Wo + mvd::C2_TW - 1) / mvd::C2_TW;
+    const int bn = mvd::c2_bn(Cout);
+    p.nblocks = (Cout + bn - 1) / bn;
+    p.ncp = p.nblocks * bn;
+    const long long tiles = (long long)p.tiles_x * p.tiles_y * B * p.nblocks * p.ncls;
+    // split K where the plain grid leaves most of the 256 CUs idle and there are chunks to share out
+    int ksplit = 1;
+    while (tiles * ksplit < 384 && ksplit < 32 && p.nchunks / (ksplit * 2) >= 2) ksplit *= 2;
+    const size_t need = (size_t)ksplit * p.ncls * B * p.Ho * p.Wo * p.ncp * sizeof(float);
+    if (ksplit > 1 && (!workspace || workspace_bytes < need)) ksplit = 1;
+    p.ksplit = ksplit;
+    p.chunks_per_split = (p.nchunks + ksplit - 1) / ksplit;
+    p.part = ksplit > 1 ? static_cast<float*>(workspace) : nullptr;
+    const long long nblk = tiles * ksplit;
+    MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv2d_split: %lld workgroups exceed the grid limit", nblk);
+    int rc = mvd::c2_dispatch(s, p, bn, nblk, st);
+    if (rc != MVD_OK || ksplit == 1) return rc;
+    const long long n = (long long)p.ncls * B * p.Ho * p.Wo * ((Cout + 3) / 4);
+    hipLaunchKernelGGL(mvd::c2_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    return mvd::launch_status("conv2d_split: reduce");
+}
+}

@@ -511,6 +511,95 @@ def softmax_regress(cost, depth_values, with_confidence=True):
     return depth, conf
 
 
+class SplitConv2dWeights:
+    """Packed split-operand weights of one 2-D layer (pack_conv2d_weights_split) with what conv2d_split needs to call it."""
+    __slots__ = ("packed", "bias", "cin", "cin_pad", "cout", "kh", "kw", "stride", "mode")
+
+    def __init__(self, packed, bias, cin, cin_pad, cout, kh, kw, stride, mode):
+        self.packed, self.bias, self.cin, self.cin_pad, self.cout = packed, bias, cin, cin_pad, cout
+        self.kh, self.kw, self.stride, self.mode = kh, kw, stride, mode
+
+
+@inference_only
+def pack_conv2d_weights_split(weight, bias=None, stride=1, mode=L.CONV2D, cin_pad=None):
+    """weight: Conv2d (Cout,Cin,k,k) (mode CONV2D / CONV2D_IMAGE) or ConvTranspose2d (Cin,Cout,4,4) (mode DECONV2D), fp32 ->
+    SplitConv2dWeights for conv2d_split.  cin_pad: the channel count of the (zero-padded) input slice the layer will read, a
+    multiple of 8 (default: Cin rounded up to 8)."""
+    lib = L.load()
+    wt = L.as_f32(weight, "weight")
+    if wt.dim() != 4:
+        raise ValueError(f"weight must be 4-D, got {tuple(wt.shape)}")
+    if mode == L.DECONV2D:
+        cin, cout = wt.shape[0], wt.shape[1]
+    else:
+        cout, cin = wt.shape[0], wt.shape[1]
+    kh, kw = wt.shape[2], wt.shape[3]
+    cin_pad = (cin + 7) // 8 * 8 if cin_pad is None else int(cin_pad)
+    nbytes = lib.mvd_conv2d_split_packed_weight_bytes(cin_pad, cout, kh, kw, stride, mode) if cin_pad >= cin else 0
+    if nbytes == 0:
+        raise ValueError(f"conv2d split: a {kh}x{kw} stride-{stride} layer (mode {mode}) with {cin} (padded {cin_pad}) -> {cout} channels is not built")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=wt.device)
+    with torch.cuda.device(wt.device):
+        rc = lib.mvd_pack_conv2d_weights_split(L.ptr(wt), cin, cin_pad, cout, kh, kw, stride, mode, L.ptr(packed), L.stream_of(wt))
+    L.check(rc, "mvd_pack_conv2d_weights_split")
+    b = None if bias is None else L.as_f32(bias.detach(), "bias", (cout,), wt.device).clone()
+    return SplitConv2dWeights(packed, b, cin, cin_pad, cout, kh, kw, stride, mode)
+
+
+def _nhwc_slice(t, name, channels=None):
+    """(B,H,W,C) fp32 device view whose pixels are `stride(2)` floats apart and dense otherwise -> (B,H,W,C, pixel stride)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
+        raise ValueError(f"{name} must be a float32 device tensor (B,H,W,C)")
+    B, H, W, C = t.shape
+    ps = t.stride(2) if W > 1 or H > 1 or B > 1 else max(C, 1)
+    if t.stride(3) != 1 or (W > 1 and t.stride(2) < C) or (H > 1 and t.stride(1) != W * ps) or (B > 1 and t.stride(0) != H * W * ps):
+        raise ValueError(f"{name}: a channel slice of a dense NHWC buffer is needed, got shape {tuple(t.shape)} strides {t.stride()}")
+    if channels is not None and C != channels:
+        raise ValueError(f"{name}: {C} channels, the layer takes {channels}")
+    return B, H, W, C, ps
+
+
+@inference_only
+def conv2d_split(x, x_absmax, wts, act=1, slope=0.2, out=None, out_absmax=None, use_workspace=True):
+    """One layer of Path A's 2-D CNN on the split-operand kernel (mvd_conv2d_split_f32).  x: (B,Hi,Wi,Cin_pad) NHWC fp32, possibly
+    a channel slice of a wider buffer (mode CONV2D_IMAGE: the planar (B,3,Hi,Wi) image); x_absmax: one-element device tensor with
+    max |x|; wts: SplitConv2dWeights.  out: NHWC destination view (B,Ho,Wo,Cout), e.g. a slice of a concat buffer (allocated if
+    None); out_absmax: one-element device tensor that receives max |out| by atomic maximum (zero it first), or None.
+    act 0 none / 1 LeakyReLU(slope) / 2 ReLU.  Returns out."""
+    lib = L.load()
+    if wts.mode == L.CONV2D_IMAGE:
+        xi = L.as_f32(x, "x")
+        if xi.dim() != 4 or xi.shape[1] != 3:
+            raise ValueError(f"x must be the planar image (B,3,H,W), got {tuple(xi.shape)}")
+        B, _, Hi, Wi = xi.shape
+        x, xs = xi, 0
+    else:
+        B, Hi, Wi, _, xs = _nhwc_slice(x, "x", wts.cin_pad)
+    if wts.mode == L.DECONV2D:
+        Ho, Wo = 2 * Hi, 2 * Wi
+    else:
+        Ho = (Hi + 2 * (wts.kh // 2) - wts.kh) // wts.stride + 1
+        Wo = (Wi + 2 * (wts.kw // 2) - wts.kw) // wts.stride + 1
+    dev = x.device
+    if out is None:
+        out = torch.empty((B, Ho, Wo, wts.cout), dtype=torch.float32, device=dev)
+    ob, oh, ow, _, ys = _nhwc_slice(out, "out", wts.cout)
+    if (ob, oh, ow) != (B, Ho, Wo):
+        raise ValueError(f"out is {tuple(out.shape)}, the layer writes ({B},{Ho},{Wo},{wts.cout})")
+    xam = L.as_f32(x_absmax, "x_absmax", (1,), dev)
+    yam = None if out_absmax is None else L.as_f32(out_absmax, "out_absmax", (1,), dev)
+    wsb = lib.mvd_conv2d_split_workspace_bytes(B, Hi, Wi, wts.cin_pad, wts.cout, wts.kh, wts.kw, wts.stride, wts.mode) if use_workspace else 0
+    if wsb > (64 << 20):  # only layers with few pixels split the reduction
+        wsb = 0
+    wsp = _workspace(wsb, dev) if wsb else None
+    with torch.cuda.device(dev):
+        rc = lib.mvd_conv2d_split_f32(L.ptr(x), L.ptr(xam), L.ptr(wts.packed), L.ptr(wts.bias), L.ptr(out), L.ptr(yam), B, Hi, Wi,
+                                      wts.cin_pad, xs, wts.cout, ys, wts.kh, wts.kw, wts.stride, wts.mode, int(act), float(slope),
+                                      L.ptr(wsp), wsb, L.stream_of(x))
+    L.check(rc, "mvd_conv2d_split_f32")
+    return out
+
+
 @inference_only
 def bias_leaky_relu_(x, bias, slope=0.2):
     """In place: x (N,C,H,W) contiguous <- leaky_relu(x + bias[c], slope).  Returns x."""

@@ -1,0 +1,125 @@
+"""GPU parity of the split-operand 2-D convolution engine (mvd_conv2d_split_f32; Path A's DispNet blocks:
+/root/reference rmvd/models/blocks/dispnet_encoder.py:6-27, dispnet_costvolume_encoder.py:7-50, dispnet_decoder.py:36-138,
+learned_fusion.py:8-20).  Each layer kind against torch's float64 convolution of the same fp32 inputs on the CPU: the bar is
+fp32-grade, i.e. no worse than what an fp32 convolution itself leaves (tolerance 3e-6 of the output scale, written below; an
+fp32 accumulation of K terms is itself off by ~1e-6 .. 1e-5 of that scale)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _reference(x_nchw, wt, bias, stride, mode, act, slope):
+    x64, w64 = x_nchw.double(), wt.double()
+    b64 = None if bias is None else bias.double()
+    if mode == 1:
+        y = F.conv_transpose2d(x64, w64, b64, stride=2, padding=1)
+    else:
+        y = F.conv2d(x64, w64, b64, stride=stride, padding=wt.shape[-1] // 2)
+    if act == 1:
+        y = F.leaky_relu(y, slope)
+    elif act == 2:
+        y = F.relu(y)
+    return y
+
+
+CASES = [
+    # (k, stride, mode, cin, cout, B, H, W, act)
+    (3, 1, 0, 32, 64, 1, 20, 37, 1),      # 3x3 stride 1, 32-channel chunks
+    (3, 1, 0, 64, 128, 2, 9, 18, 1),
+    (3, 1, 0, 26, 32, 1, 17, 16, 1),      # Cin + 2 not a multiple of 8: padded slice, 8-channel chunks
+    (3, 1, 0, 98, 32, 1, 33, 21, 1),      # rfeat5's channel count
+    (3, 1, 0, 32, 2, 1, 19, 30, 0),       # a prediction head: 2 output channels, no activation
+    (3, 1, 0, 128, 1, 2, 12, 18, 0),      # (the fusion block's 1x1 has 128 -> 1; here 3x3)
+    (3, 2, 0, 16, 32, 1, 32, 48, 1),      # 3x3 stride 2
+    (3, 2, 0, 64, 256, 2, 14, 22, 1),
+    (5, 2, 0, 8, 16, 1, 40, 36, 1),       # 5x5 stride 2
+    (5, 2, 0, 64, 128, 1, 30, 34, 1),
+    (1, 1, 0, 64, 32, 1, 13, 29, 1),      # 1x1
+    (1, 1, 0, 128, 1, 2, 12, 18, 0),
+    (4, 2, 1, 32, 16, 1, 9, 14, 1),       # transposed 4x4 stride 2
+    (4, 2, 1, 64, 32, 2, 16, 16, 1),
+    (7, 2, 2, 3, 64, 2, 38, 52, 1),       # the first layer on the planar image
+    (3, 1, 0, 512, 256, 1, 6, 9, 1),      # few pixels, many weights: the reduction is split over workgroups
+    (3, 2, 0, 256, 512, 1, 12, 18, 1),
+    (4, 2, 1, 512, 256, 1, 3, 5, 2),
+    (3, 1, 0, 64, 64, 1, 16, 16, 2),      # ReLU
+]
+
+
+@pytest.mark.parametrize("k,stride,mode,cin,cout,B,H,W,act", CASES)
+def test_conv2d_split_vs_float64(k, stride, mode, cin, cout, B, H, W, act, dev):
+    from robustmvd_amd import ops
+    g = torch.Generator().manual_seed(k * 1000 + cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g) * torch.rand(1, cin, 1, 1, generator=g) * 4
+    wshape = (cin, cout, 4, 4) if mode == 1 else (cout, cin, k, k)
+    wt = torch.randn(*wshape, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    slope = 0.2
+    want = _reference(x, wt, bias, stride, mode, act, slope)
+    wts = ops.pack_conv2d_weights_split(wt.to(dev), bias.to(dev), stride=stride, mode=mode)
+    assert wts.cin_pad % 8 == 0 and wts.cin_pad >= cin
+    if mode == 2:
+        xin = x.to(dev)
+    else:  # NHWC slice of a wider buffer: channels [4, 4 + cin_pad) of cin_pad + 12, pad channels zero
+        buf = torch.full((B, H, W, wts.cin_pad + 12), 7.0, device=dev)
+        buf[..., 4:4 + wts.cin_pad] = 0
+        buf[..., 4:4 + cin] = x.permute(0, 2, 3, 1).to(dev)
+        xin = buf[..., 4:4 + wts.cin_pad]
+    Ho, Wo = want.shape[-2:]
+    obuf = torch.full((B, Ho, Wo, cout + 8 if cout >= 4 else cout), -3.0, device=dev)
+    out = obuf[..., 4:4 + cout] if cout >= 4 else obuf
+    amax = torch.zeros(1, device=dev)
+    got = ops.conv2d_split(xin, ops.absmax(x.to(dev)), wts, act=act, slope=slope, out=out, out_absmax=amax)
+    assert got.data_ptr() == out.data_ptr()
+    y = got.permute(0, 3, 1, 2).double().cpu()
+    scale = float(want.abs().max())
+    err = float((y - want).abs().max())
+    assert err <= 3e-6 * scale, (err, scale)
+    assert float(amax) == float(got.abs().max())
+    if cout >= 4:  # the neighbouring channels of the destination buffer are untouched
+        assert float(obuf[..., :4].min()) == -3.0 and float(obuf[..., 4 + cout:].max()) == -3.0
+    # allocated output, no workspace (no split of the reduction): same values up to fp32 summation order
+    got2 = ops.conv2d_split(xin, ops.absmax(x.to(dev)), wts, act=act, slope=slope, use_workspace=False)
+    assert tuple(got2.shape) == (B, Ho, Wo, cout)
+    assert float((got2.permute(0, 3, 1, 2).double().cpu() - want).abs().max()) <= 3e-6 * scale
+
+
+@pytest.mark.parametrize("mag", [1e-30, 1e-8, 1.0, 1e4, 1e20])
+def test_conv2d_split_range(mag, dev):
+    """Block scaling: the same relative accuracy whatever the magnitude of the activations and of the weights."""
+    from robustmvd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 32, 12, 20, generator=g) * mag
+    wt = torch.randn(16, 32, 3, 3, generator=g) * (1e-3 / mag if mag > 1 else 1e3)
+    want = F.conv2d(x.double(), wt.double(), padding=1)
+    wts = ops.pack_conv2d_weights_split(wt.to(dev))
+    got = ops.conv2d_split(x.permute(0, 2, 3, 1).contiguous().to(dev), ops.absmax(x.to(dev)), wts, act=0)
+    err = float((got.permute(0, 3, 1, 2).double().cpu() - want).abs().max())
+    assert err <= 3e-6 * float(want.abs().max())
+
+
+def test_conv2d_split_is_deterministic_and_refuses_bad_arguments(dev):
+    from robustmvd_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 6, 9, 512, generator=g).to(dev)
+    wt = (torch.randn(256, 512, 3, 3, generator=g) * 0.02).to(dev)
+    wts = ops.pack_conv2d_weights_split(wt)
+    am = ops.absmax(x)
+    a = ops.conv2d_split(x, am, wts)
+    b = ops.conv2d_split(x, am, wts)
+    assert torch.equal(a, b)  # the split reduction adds its partial sums in a fixed order
+    with pytest.raises(ValueError, match="not built"):
+        ops.pack_conv2d_weights_split(torch.zeros(8, 8, 2, 2, device=dev))
+    with pytest.raises(ValueError, match="channels"):
+        ops.conv2d_split(x[..., :64], am, wts)
+    with pytest.raises(ValueError, match="slice"):
+        ops.conv2d_split(x.permute(0, 2, 1, 3), am, wts)
