@@ -102,6 +102,14 @@ int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, c
                           int invdepth_mode, float corr_scale, int N, int C, int h, int w, int hs, int ws, int S, int V,
                           float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
                           mvd_stream_t stream);
+/* K1 on the layouts the kernel works in, without the re-packing launches: feat_key (N,h,w,C) channel-last, feat_src[v] zero-bordered
+ * channel-last (N,hs+3,ws+3,C) with the map at rows/columns 1.. (what mvd_conv2d_split_f32 writes with its row/image strides),
+ * outputs pixel-major: corr_out[v][(n h w + pixel) * out_pixel_stride + s] (and mask_out alike), i.e. (N,h,w,S) maps that the
+ * 2-D convolutions behind the sweep read as S channels.  No workspace. */
+int mvd_sweep_corr_nhwc_f32(const float* feat_key, const float* const* feat_src, const float* K_key, const float* const* K_src,
+                            const float* const* T_src2key, const float* invdepths, int invdepth_mode, float corr_scale, int N, int C,
+                            int h, int w, int hs, int ws, int S, int V, float* const* corr_out, float* const* mask_out,
+                            int out_pixel_stride, mvd_stream_t stream);
 
 /* The sweep of PlanesweepCorrelation(warp_only=True) — replaces WarpOnlyCorr.forward + warp_multi
  *   rmvd/models/blocks/planesweep_corr.py:107-140, 13-45 (reached through correlate(), :514-521):
@@ -122,6 +130,12 @@ int mvd_sweep_warp_f32(const float* const* feat_src, const float* K_key, const f
  *   corr, mask  V x (N,S,h,w);  score  V x (N,1,h,w);  fused, fused_mask  (N,S,h,w) */
 int mvd_fuse_views_f32(const float* const* corr, const float* const* mask, const float* const* score, int N, int S,
                        int h, int w, int V, float* fused, float* fused_mask, mvd_stream_t stream);
+/* K2 on pixel-major volumes (N,h,w,S) with pixels in_pixel_stride floats apart (mvd_sweep_corr_nhwc_f32's outputs); score[v]
+ * (N,1,h,w).  fused: channel slice of a channel-last buffer (pixels out_pixel_stride floats apart); fused_mask NULL or the same
+ * layout; fused_absmax NULL or a device float receiving max |fused| by atomic maximum (the caller zeroes it). */
+int mvd_fuse_views_nhwc_f32(const float* const* corr, const float* const* mask, const float* const* score, int N, int S, int h,
+                            int w, int V, int in_pixel_stride, float* fused, float* fused_mask, int out_pixel_stride,
+                            float* fused_absmax, mvd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Path B (mvsnet): fronto-parallel homography warp, variance aggregation, 3-D regulariser, soft argmin
@@ -246,7 +260,10 @@ int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const vo
  * x_absmax: device float, max |x| over the input tensor (an upper bound is safe); y_absmax: NULL, or a device float that
  * receives max |y| by atomic maximum (the caller zeroes it; several layers may share one to cover a concat buffer).
  * act: 0 none, 1 LeakyReLU(slope), 2 ReLU; bias NULL or (Cout).  workspace: NULL, or mvd_conv2d_split_workspace_bytes bytes:
- * lets layers with few pixels and many weights split the reduction over workgroups (partial sums added in a fixed order). */
+ * lets layers with few pixels and many weights split the reduction over workgroups (partial sums added in a fixed order).
+ * Output strides (floats): y_pixel_stride between pixels; y_row_stride / y_image_stride between rows / images (0 = dense: a layer
+ * may write the interior of a zero-bordered map, which is what mvd_sweep_corr_nhwc_f32 reads); y_channel_stride between channels
+ * (0 or 1 = channel-last; with y_pixel_stride = 1 and y_channel_stride = Ho Wo the output is planar (B,Cout,Ho,Wo)). */
 #define MVD_CONV2D 0
 #define MVD_DECONV2D 1
 #define MVD_CONV2D_IMAGE 2
@@ -255,8 +272,13 @@ int mvd_pack_conv2d_weights_split(const float* w, int Cin, int Cin_pad, int Cout
                                   mvd_stream_t stream);
 size_t mvd_conv2d_split_workspace_bytes(int B, int Hi, int Wi, int Cin_pad, int Cout, int KH, int KW, int stride, int mode);
 int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* packed_w, const float* bias, float* y, float* y_absmax, int B,
-                         int Hi, int Wi, int Cin_pad, int x_pixel_stride, int Cout, int y_pixel_stride, int KH, int KW, int stride, int mode,
-                         int act, float slope, void* workspace, size_t workspace_bytes, mvd_stream_t stream);
+                         int Hi, int Wi, int Cin_pad, int x_pixel_stride, int Cout, int y_pixel_stride, long long y_row_stride,
+                         long long y_image_stride, long long y_channel_stride, int KH, int KW, int stride, int mode, int act, float slope,
+                         void* workspace, size_t workspace_bytes, mvd_stream_t stream);
+/* F.interpolate(x, size=(2h,2w), mode="bilinear", align_corners=False) of a planar (B,C,h,w) map (the decoder's up-sampled
+ * prediction, dispnet_decoder.py:131), written as C channels of a channel-last slice y (pixels y_pixel_stride floats apart);
+ * torch's formula and operation order.  y_absmax as above (NULL or atomic maximum). */
+int mvd_upsample2x_nhwc_f32(const float* x, float* y, float* y_absmax, int B, int C, int h, int w, int y_pixel_stride, mvd_stream_t stream);
 /* max |x[i]| over the FINITE values of n floats (inf and NaN left out, 0 if there is none) into *absmax (device, one
  * float); a streaming read */
 int mvd_absmax_f32(const float* x, long long n, float* absmax, mvd_stream_t stream);

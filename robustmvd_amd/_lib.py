@@ -45,6 +45,10 @@ SIGNATURES = {
                            + [_pp, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
     "mvd_sweep_corr_ex_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, ctypes.c_float] + [_i] * 8
                               + [_pp, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "mvd_sweep_corr_nhwc_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, ctypes.c_float] + [_i] * 8
+                                + [_pp, _pp, _i, ctypes.c_void_p]),
+    "mvd_fuse_views_nhwc_f32": (_i, [_pp, _pp, _pp] + [_i] * 6 + [_c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p]),
+    "mvd_upsample2x_nhwc_f32": (_i, [_c_float_p, _c_float_p, _c_float_p] + [_i] * 5 + [ctypes.c_void_p]),
     "mvd_sweep_warp_f32": (_i, [_pp, _c_float_p, _pp, _pp, _c_float_p] + [_i] * 10 + [_pp, _pp, ctypes.c_void_p]),
     "mvd_fuse_views_f32": (_i, [_pp, _pp, _pp, _i, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "mvd_warp_variance_workspace_bytes": (_sz, [_i] * 5),
@@ -71,8 +75,8 @@ SIGNATURES = {
     "mvd_conv2d_split_packed_weight_bytes": (_sz, [_i] * 6),
     "mvd_pack_conv2d_weights_split": (_i, [_c_float_p] + [_i] * 7 + [ctypes.c_void_p, ctypes.c_void_p]),
     "mvd_conv2d_split_workspace_bytes": (_sz, [_i] * 9),
-    "mvd_conv2d_split_f32": (_i, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 12
-                             + [ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "mvd_conv2d_split_f32": (_i, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7
+                             + [ctypes.c_longlong] * 3 + [_i] * 5 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "mvd_pack_conv3d_weights_split": (_i, [_c_float_p, _i, _i, ctypes.c_void_p, ctypes.c_void_p]),
     "mvd_conv3d_bn_relu_f32_split": (_i, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7
                                      + [ctypes.c_void_p]),

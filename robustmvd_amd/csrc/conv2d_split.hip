@@ -26,6 +26,7 @@
 //
 // Transposed convolutions (4 x 4, stride 2, padding 1) run as four 2 x 2 stride-1 layers, one per output parity class.
 #include "mvd_common.h"
+#include <algorithm>
 
 namespace mvd {
 
@@ -62,7 +63,8 @@ struct C2Params {
     float* part;          // split-K: partial sums [ksplit][B Ho Wo][ncp]; NULL = direct epilogue
     int B, Hi, Wi, xs, nchunks;
     int Ho, Wo;           // output grid of this launch (transposed conv: one parity class = the input grid)
-    int Hy, Wy, ys;       // the output tensor's full grid
+    int Hy, Wy, ys;       // the output tensor's full grid; floats between pixels
+    long long ys_row, ys_img, ycs;  // floats between output rows, images and channels (ycs = 1: channel-last)
     int oy_mul, ox_mul;   // output pixel (oy, ox) of the grid lands at (oy * oy_mul + a, ox * ox_mul + b)
     int pad_y, pad_x;     // input row of tap ky for output row oy: oy * S - pad_y + ky
     int Cout, ncp;        // output channels; ncp = Cout padded to the launch's BN
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
             for (int m = 0; m < MTW; ++m) {
                 const int oy = oy0 + wm * MTW + m;
                 if (oy >= p.Ho) continue;
-                float* dst = p.y + (((size_t)b * p.Hy + (size_t)oy * p.oy_mul + ca) * p.Wy + (size_t)ox * p.ox_mul + cb2) * p.ys + cb;
+                float* dst = p.y + (size_t)b * p.ys_img + ((size_t)oy * p.oy_mul + ca) * p.ys_row + ((size_t)ox * p.ox_mul + cb2) * p.ys + cb * p.ycs;
                 float r4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -331,12 +333,12 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
                     r4[r] = v;
                     if (cb + r < p.Cout) amax = fmaxf(amax, finite_abs_or_zero(v));
                 }
-                if (cb + 3 < p.Cout) {
+                if (cb + 3 < p.Cout && p.ycs == 1) {
                     *reinterpret_cast<c2f4*>(dst) = c2f4{r4[0], r4[1], r4[2], r4[3]};
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (cb + r < p.Cout) dst[r] = r4[r];
+                        if (cb + r < p.Cout) dst[r * p.ycs] = r4[r];
                 }
             }
     }
@@ -356,32 +358,42 @@ __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
     __shared__ float wmax[4];
     const long long npix = (long long)p.B * p.Ho * p.Wo;
     const int c4n = (p.Cout + 3) / 4;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float xsc_inv;
+    {
+        const unsigned mb = __float_as_uint(*p.xamax);
+        const int ex = (int)((mb >> 23) & 0xffu) - 127;
+        const int e = max(-125, min(125, ex - 14));
+        xsc_inv = __uint_as_float((unsigned)(127 + e) << 23);
+    }
     float amax = 0.f;
-    if (i < npix * c4n * p.ncls) {
+    // grid-stride: at most a few hundred workgroups, each ends with ONE atomic (they serialise on the address)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix * c4n * p.ncls; i += (long long)gridDim.x * 256) {
         const int cls = (int)(i / (npix * c4n));
         const long long pl = (i / c4n) % npix;
         const int cb = (int)(i % c4n) * 4;
         c2f4 s = c2f4{0, 0, 0, 0};
         for (int ks = 0; ks < p.ksplit; ++ks)
             s += *reinterpret_cast<const c2f4*>(p.part + (((size_t)cls * p.ksplit + ks) * npix + pl) * p.ncp + cb);
-        float xsc_inv;
-        {
-            const unsigned mb = __float_as_uint(*p.xamax);
-            const int ex = (int)((mb >> 23) & 0xffu) - 127;
-            const int e = max(-125, min(125, ex - 14));
-            xsc_inv = __uint_as_float((unsigned)(127 + e) << 23);
-        }
         const int ox = (int)(pl % p.Wo), oy = (int)((pl / p.Wo) % p.Ho), b = (int)(pl / ((long long)p.Wo * p.Ho));
-        float* dst = p.y + (((size_t)b * p.Hy + (size_t)oy * p.oy_mul + (cls >> 1)) * p.Wy + (size_t)ox * p.ox_mul + (cls & 1)) * p.ys + cb;
+        float* dst = p.y + (size_t)b * p.ys_img + ((size_t)oy * p.oy_mul + (cls >> 1)) * p.ys_row + ((size_t)ox * p.ox_mul + (cls & 1)) * p.ys + cb * p.ycs;
+        float r4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (cb + r >= p.Cout) break;
-            float v = fmaf(s[r], p.eun[cb + r] * xsc_inv, p.bias ? p.bias[cb + r] : 0.f);
-            if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-            else if (p.act == 2) v = fmaxf(v, 0.f);
-            dst[r] = v;
-            amax = fmaxf(amax, finite_abs_or_zero(v));
+            float v = 0.f;
+            if (cb + r < p.Cout) {
+                v = fmaf(s[r], p.eun[cb + r] * xsc_inv, p.bias ? p.bias[cb + r] : 0.f);
+                if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+                else if (p.act == 2) v = fmaxf(v, 0.f);
+                amax = fmaxf(amax, finite_abs_or_zero(v));
+            }
+            r4[r] = v;
+        }
+        if (cb + 3 < p.Cout && p.ycs == 1) {
+            *reinterpret_cast<c2f4*>(dst) = c2f4{r4[0], r4[1], r4[2], r4[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (cb + r < p.Cout) dst[r * p.ycs] = r4[r];
         }
     }
     if (p.yamax) {
@@ -391,6 +403,39 @@ __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
         if (threadIdx.x == 0) {
             amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
             if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.yamax), __float_as_uint(amax));
+        }
+    }
+}
+
+// F.interpolate(pred, size = (2h, 2w), mode = "bilinear", align_corners = False) of the decoder (dispnet_decoder.py:131), written
+// as C channels of a channel-last slice: x planar (B, C, h, w) -> y[b][oy][ox][0 .. C-1], pixels ys floats apart.  torch's own
+// formula and operation order (source index max(0.5 (o + 0.5) - 0.5, 0), the two lambdas, rows blended after columns).
+__global__ void __launch_bounds__(256) upsample2x_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, float* yamax, int B, int C, int h,
+                                                              int w, int ys) {
+    __shared__ float wmax[4];
+    const long long n = (long long)B * 4 * h * w;
+    float amax = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % (2 * w)), oy = (int)((i / (2 * w)) % (2 * h)), b = (int)(i / (4LL * h * w));
+        const float sy = fmaxf(0.5f * ((float)oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)ox + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+        for (int c = 0; c < C; ++c) {
+            const float* pl = x + ((size_t)b * C + c) * h * w;
+            const float v = ly0 * (lx0 * pl[(size_t)y0 * w + x0] + lx1 * pl[(size_t)y0 * w + x1]) +
+                            ly1 * (lx0 * pl[(size_t)y1 * w + x0] + lx1 * pl[(size_t)y1 * w + x1]);
+            y[(size_t)i * ys + c] = v;
+            amax = fmaxf(amax, finite_abs_or_zero(v));
+        }
+    }
+    if (yamax) {
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(yamax), __float_as_uint(amax));
         }
     }
 }
@@ -435,6 +480,31 @@ static size_t c2_frag_bytes(const C2Shape& s, int cin_pad, int cout) {
     return (s.transposed ? 4 : 1) * (size_t)c2_ntiles(cout) * nchunks * s.steps * 2048;
 }
 static int c2_cpad(int cout) { return (cout + 127) / 128 * 128; }  // eun entries: any BN reads whole float4s
+
+// grid of one layer: output size, channel tile, and over how many workgroups the reduction is split (where the plain grid would
+// leave most of the 256 CUs idle and there are chunks to share out)
+struct C2Plan {
+    int Ho, Wo, tiles_x, tiles_y, bn, nblocks, ncp, ncls, nchunks, ksplit;
+    long long tiles;
+    size_t part_bytes;
+};
+static C2Plan c2_plan(const C2Shape& s, int B, int Hi, int Wi, int cin_pad, int cout, int KH, int KW, int stride) {
+    C2Plan q{};
+    if (s.transposed) { q.Ho = Hi; q.Wo = Wi; q.ncls = 4; }
+    else { q.Ho = (Hi + 2 * (KH / 2) - KH) / stride + 1; q.Wo = (Wi + 2 * (KW / 2) - KW) / stride + 1; q.ncls = 1; }
+    q.tiles_y = (q.Ho + C2_TH - 1) / C2_TH;
+    q.tiles_x = (q.Wo + C2_TW - 1) / C2_TW;
+    q.bn = c2_bn(cout);
+    q.nblocks = (cout + q.bn - 1) / q.bn;
+    q.ncp = q.nblocks * q.bn;
+    q.nchunks = cin_pad / (8 * s.U8);
+    q.tiles = (long long)q.tiles_x * q.tiles_y * B * q.nblocks * q.ncls;
+    q.ksplit = 1;  // a grid of 128+ workgroups runs as it is: the second pass would cost more than the idle CUs
+    if (q.tiles < 128)
+        while (q.tiles * q.ksplit < 320 && q.ksplit < 32 && q.nchunks / (q.ksplit * 2) >= 2) q.ksplit *= 2;
+    q.part_bytes = q.ksplit > 1 ? (size_t)q.ksplit * q.ncls * B * q.Ho * q.Wo * q.ncp * sizeof(float) : 0;
+    return q;
+}
 
 template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
 static int c2_launch(const C2Params& p, long long nblk, hipStream_t st) {
@@ -498,16 +568,15 @@ int mvd_pack_conv2d_weights_split(const float* w, int Cin, int Cin_pad, int Cout
 }
 
 size_t mvd_conv2d_split_workspace_bytes(int B, int Hi, int Wi, int Cin_pad, int Cout, int KH, int KW, int stride, int mode) {
-    // upper bound over the split the launcher may choose: 32 partial sums per output
     mvd::C2Shape s;
-    if (!mvd::c2_shape(KH, KW, stride, mode, Cin_pad, &s)) return 0;
-    const long long Ho = mode == 1 ? Hi : (Hi + 2 * (KH / 2) - KH) / stride + 1, Wo = mode == 1 ? Wi : (Wi + 2 * (KW / 2) - KW) / stride + 1;
-    return (size_t)32 * (mode == 1 ? 4 : 1) * B * Ho * Wo * mvd::c2_cpad(Cout) * sizeof(float);
+    if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin_pad <= 0 || Cout <= 0 || !mvd::c2_shape(KH, KW, stride, mode, Cin_pad, &s)) return 0;
+    return mvd::c2_plan(s, B, Hi, Wi, Cin_pad, Cout, KH, KW, stride).part_bytes;
 }
 
 int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* packed_w, const float* bias, float* y, float* y_absmax, int B,
-                         int Hi, int Wi, int Cin_pad, int x_pixel_stride, int Cout, int y_pixel_stride, int KH, int KW, int stride, int mode,
-                         int act, float slope, void* workspace, size_t workspace_bytes, mvd_stream_t stream) {
+                         int Hi, int Wi, int Cin_pad, int x_pixel_stride, int Cout, int y_pixel_stride, long long y_row_stride,
+                         long long y_image_stride, long long y_channel_stride, int KH, int KW, int stride, int mode, int act, float slope,
+                         void* workspace, size_t workspace_bytes, mvd_stream_t stream) {
     MVD_REQUIRE(x && x_absmax && packed_w && y, "conv2d_split: NULL argument");
     MVD_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "conv2d_split: non-positive dimension");
     mvd::C2Shape s;
@@ -515,7 +584,9 @@ int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* pack
                 "conv2d_split: layer %dx%d stride %d mode %d with %d -> %d channels is not built", KH, KW, stride, mode, Cin_pad, Cout);
     MVD_REQUIRE(mode == 2 || (x_pixel_stride >= Cin_pad && x_pixel_stride % 4 == 0), "conv2d_split: input pixel stride %d (channels %d)",
                 x_pixel_stride, Cin_pad);
-    MVD_REQUIRE(y_pixel_stride >= Cout, "conv2d_split: output pixel stride %d below %d channels", y_pixel_stride, Cout);
+    if (y_channel_stride <= 0) y_channel_stride = 1;
+    MVD_REQUIRE(y_channel_stride != 1 || y_pixel_stride >= Cout, "conv2d_split: output pixel stride %d below %d channels", y_pixel_stride, Cout);
+    MVD_REQUIRE(y_pixel_stride >= 1 && y_row_stride >= 0 && y_image_stride >= 0, "conv2d_split: negative output stride");
     MVD_REQUIRE(act >= 0 && act <= 2, "conv2d_split: act=%d unknown", act);
     MVD_REQUIRE(mode == 2 || (((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0), "conv2d_split: x and y must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -525,27 +596,27 @@ int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* pack
     p.Cout = Cout; p.ys = y_pixel_stride; p.act = act; p.slope = slope;
     const size_t fb = mvd::c2_frag_bytes(s, Cin_pad, Cout);
     p.eun = reinterpret_cast<const float*>(static_cast<const char*>(packed_w) + fb);
+    const mvd::C2Plan q = mvd::c2_plan(s, B, Hi, Wi, Cin_pad, Cout, KH, KW, stride);
+    p.Ho = q.Ho; p.Wo = q.Wo; p.ncls = q.ncls;
     if (s.transposed) {
-        p.Ho = Hi; p.Wo = Wi; p.Hy = 2 * Hi; p.Wy = 2 * Wi; p.oy_mul = p.ox_mul = 2; p.pad_y = p.pad_x = 1; p.ncls = 4;
+        p.Hy = 2 * Hi; p.Wy = 2 * Wi; p.oy_mul = p.ox_mul = 2; p.pad_y = p.pad_x = 1;
     } else {
-        const int ph = KH / 2, pw = KW / 2;
-        p.Ho = (Hi + 2 * ph - KH) / stride + 1; p.Wo = (Wi + 2 * pw - KW) / stride + 1;
-        p.Hy = p.Ho; p.Wy = p.Wo; p.oy_mul = p.ox_mul = 1; p.pad_y = ph; p.pad_x = pw; p.ncls = 1;
+        p.Hy = p.Ho; p.Wy = p.Wo; p.oy_mul = p.ox_mul = 1; p.pad_y = KH / 2; p.pad_x = KW / 2;
     }
-    MVD_REQUIRE((y_pixel_stride % 4 == 0) || Cout < 4, "conv2d_split: output pixel stride %d must be a multiple of 4", y_pixel_stride);
+    MVD_REQUIRE(y_channel_stride != 1 || Cout < 4 || (y_pixel_stride % 4 == 0 && y_row_stride % 4 == 0 && y_image_stride % 4 == 0),
+                "conv2d_split: channel-last output strides must be multiples of 4 floats");
+    p.ycs = y_channel_stride;
+    p.ys_row = y_row_stride > 0 ? y_row_stride : (long long)p.Wy * y_pixel_stride;
+    p.ys_img = y_image_stride > 0 ? y_image_stride : (long long)p.Hy * p.ys_row;
     p.wpk = static_cast<const char*>(packed_w);
     p.cls_bytes = (long long)(fb / p.ncls);
-    p.tiles_y = (p.Ho + mvd::C2_TH - 1) / mvd::C2_TH;
-    p.tiles_x = (p.Wo + mvd::C2_TW - 1) / mvd::C2_TW;
-    const int bn = mvd::c2_bn(Cout);
-    p.nblocks = (Cout + bn - 1) / bn;
-    p.ncp = p.nblocks * bn;
-    const long long tiles = (long long)p.tiles_x * p.tiles_y * B * p.nblocks * p.ncls;
-    // split K where the plain grid leaves most of the 256 CUs idle and there are chunks to share out
-    int ksplit = 1;
-    while (tiles * ksplit < 384 && ksplit < 32 && p.nchunks / (ksplit * 2) >= 2) ksplit *= 2;
-    const size_t need = (size_t)ksplit * p.ncls * B * p.Ho * p.Wo * p.ncp * sizeof(float);
-    if (ksplit > 1 && (!workspace || workspace_bytes < need)) ksplit = 1;
+    p.tiles_y = q.tiles_y; p.tiles_x = q.tiles_x;
+    const int bn = q.bn;
+    p.nblocks = q.nblocks;
+    p.ncp = q.ncp;
+    const long long tiles = q.tiles;
+    int ksplit = q.ksplit;
+    if (ksplit > 1 && (!workspace || workspace_bytes < q.part_bytes)) ksplit = 1;  // no workspace: the plain grid
     p.ksplit = ksplit;
     p.chunks_per_split = (p.nchunks + ksplit - 1) / ksplit;
     p.part = ksplit > 1 ? static_cast<float*>(workspace) : nullptr;
@@ -554,7 +625,16 @@ int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* pack
     int rc = mvd::c2_dispatch(s, p, bn, nblk, st);
     if (rc != MVD_OK || ksplit == 1) return rc;
     const long long n = (long long)p.ncls * B * p.Ho * p.Wo * ((Cout + 3) / 4);
-    hipLaunchKernelGGL(mvd::c2_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(mvd::c2_reduce_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 512)), dim3(256), 0, st, p);
     return mvd::launch_status("conv2d_split: reduce");
+}
+
+int mvd_upsample2x_nhwc_f32(const float* x, float* y, float* y_absmax, int B, int C, int h, int w, int y_pixel_stride, mvd_stream_t stream) {
+    MVD_REQUIRE(x && y, "upsample2x_nhwc: NULL argument");
+    MVD_REQUIRE(B > 0 && C > 0 && h > 0 && w > 0 && y_pixel_stride >= C, "upsample2x_nhwc: bad dimension");
+    const long long n = (long long)B * 4 * h * w;
+    hipLaunchKernelGGL(mvd::upsample2x_nhwc_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       y_absmax, B, C, h, w, y_pixel_stride);
+    return mvd::launch_status("upsample2x_nhwc");
 }
 }

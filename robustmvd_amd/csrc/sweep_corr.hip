@@ -34,6 +34,7 @@ struct SweepParams {
     int invd_per_pixel;  // planesweep_corr.py:465-487 accepts (N,S), (N,S,H) and (N,S,H,W) sampling inverse depths
     float corr_scale;    // 1/sqrt(C) for normalize="dim" (planesweep_corr.py:186), 1 otherwise
     int N, h, w, hs, ws, S, V;
+    int out_ps;          // 0: outputs (N,S,h,w); > 0: pixel-major (N,h,w,S) with pixels out_ps floats apart (mvd_sweep_corr_nhwc_f32)
 };
 
 constexpr int SWEEP_PX = 16;  // key pixels per workgroup
@@ -245,6 +246,18 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
     float* __restrict__ co = p.corr.p[v] + ((size_t)n * S * h + y) * w + x0;
     float* __restrict__ mo = p.mask.p[v] + ((size_t)n * S * h + y) * w + x0;
     const size_t plane = (size_t)h * w;
+    if (p.out_ps > 0) {  // pixel-major: the S values of a pixel are contiguous (what the 2-D convolutions after the sweep read)
+        float* __restrict__ cn = p.corr.p[v] + (((size_t)n * h + y) * w + x0) * p.out_ps;
+        float* __restrict__ mn = p.mask.p[v] + (((size_t)n * h + y) * w + x0) * p.out_ps;
+        for (int e = tid; e < S * SWEEP_PX; e += 256) {
+            const int px = e / S, s = e % S;
+            if (px < npx) {
+                cn[(size_t)px * p.out_ps + s] = res[s * SWEEP_PX + px];
+                mn[(size_t)px * p.out_ps + s] = res[(S + s) * SWEEP_PX + px];
+            }
+        }
+        return;
+    }
     for (int e = tid; e < S * SWEEP_PX; e += 256) {
         const int s = e / SWEEP_PX, px = e % SWEEP_PX;
         if (px < npx) {
@@ -344,40 +357,14 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
                                  C, h, w, hs, ws, S, V, corr_out, mask_out, workspace, workspace_bytes, stream);
 }
 
-int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
-                          const float* const* K_src, const float* const* T_src2key, const float* invdepths,
-                          int invdepth_mode, float corr_scale, int N, int C, int h, int w, int hs, int ws, int S, int V,
-                          float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
-                          mvd_stream_t stream) {
-    MVD_REQUIRE(invdepth_mode == MVD_INVDEPTH_SHARED || invdepth_mode == MVD_INVDEPTH_BATCHED || invdepth_mode == MVD_INVDEPTH_PER_PIXEL,
-                "sweep_corr: invdepth_mode %d", invdepth_mode);
-    MVD_REQUIRE(feat_key && feat_src && K_key && K_src && T_src2key && invdepths && corr_out && mask_out,
-                "sweep_corr: NULL argument");
-    MVD_REQUIRE(N > 0 && h > 0 && w > 0 && hs > 0 && ws > 0 && S > 0, "sweep_corr: non-positive dimension");
-    MVD_REQUIRE(V >= 1 && V <= MVD_MAX_VIEWS, "sweep_corr: V=%d outside 1..%d", V, MVD_MAX_VIEWS);
-    MVD_REQUIRE(C % 64 == 0 && C >= 64 && C <= 512, "sweep_corr: C=%d must be a multiple of 64 in 64..512", C);
-    MVD_REQUIRE((long long)(hs + 3) * (ws + 3) * C < 0x7fffffffLL, "sweep_corr: source map %dx%dx%d too large", hs, ws, C);
-    MVD_REQUIRE(h <= 65535 && (long long)N * V <= 65535, "sweep_corr: h or N*V exceeds 65535");
+static int sweep_corr_run(const float* key_nhwc, const float* const* src_bordered, const float* K_key, const float* const* K_src,
+                          const float* const* T_src2key, const float* invdepths, int invdepth_mode, float corr_scale, int N, int C, int h,
+                          int w, int hs, int ws, int S, int V, float* const* corr_out, float* const* mask_out, int out_ps, hipStream_t st) {
     const size_t lds = (size_t)2 * S * mvd::SWEEP_PX * sizeof(float);
-    MVD_REQUIRE(lds <= 160 * 1024, "sweep_corr: S=%d needs %zu B of LDS (> 160 KiB)", S, lds);
-    const size_t need = mvd_sweep_corr_workspace_bytes(N, C, h, w, hs, ws, V);
-    if (!workspace || workspace_bytes < need) {
-        mvd::set_error("sweep_corr: workspace %zu B < required %zu B", workspace_bytes, need);
-        return MVD_ERR_WORKSPACE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    float* wsp = (float*)workspace;
     mvd::SweepParams p{};
-    int rc = mvd::transpose_launch(feat_key, wsp, N, C, (long long)h * w, st);
-    if (rc) return rc;
-    p.key = wsp;
-    wsp += mvd::align_up((size_t)N * C * h * w * sizeof(float), 256) / sizeof(float);
-    const size_t per = mvd::padded_slot_bytes_public(N, C, hs, ws) / sizeof(float);
+    p.key = key_nhwc;
     for (int v = 0; v < V; ++v) {
-        MVD_REQUIRE(feat_src[v] && K_src[v] && T_src2key[v] && corr_out[v] && mask_out[v], "sweep_corr: NULL view %d", v);
-        rc = mvd::repack_padded_launch(feat_src[v], wsp + v * per, N, C, hs, ws, st);
-        if (rc) return rc;
-        p.src.p[v] = wsp + v * per;
+        p.src.p[v] = src_bordered[v];
         p.K_src.p[v] = K_src[v];
         p.T.p[v] = T_src2key[v];
         p.corr.p[v] = corr_out[v];
@@ -389,6 +376,7 @@ int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, c
     p.invd_per_pixel = invdepth_mode == MVD_INVDEPTH_PER_PIXEL;
     p.corr_scale = corr_scale;
     p.N = N; p.h = h; p.w = w; p.hs = hs; p.ws = ws; p.S = S; p.V = V;
+    p.out_ps = out_ps;
     dim3 grid((unsigned)((w + mvd::SWEEP_PX - 1) / mvd::SWEEP_PX), (unsigned)h, (unsigned)(N * V));
     mvd::timing_begin(st);
     switch (C / 64) {
@@ -405,6 +393,65 @@ int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, c
     }
     mvd::timing_end(st);
     return mvd::launch_status("sweep_corr");
+}
+
+static int sweep_corr_check(const void* feat_key, const void* feat_src, const void* K_key, const void* K_src, const void* T_src2key,
+                            const void* invdepths, int invdepth_mode, int N, int C, int h, int w, int hs, int ws, int S, int V,
+                            const void* corr_out, const void* mask_out) {
+    MVD_REQUIRE(invdepth_mode == MVD_INVDEPTH_SHARED || invdepth_mode == MVD_INVDEPTH_BATCHED || invdepth_mode == MVD_INVDEPTH_PER_PIXEL,
+                "sweep_corr: invdepth_mode %d", invdepth_mode);
+    MVD_REQUIRE(feat_key && feat_src && K_key && K_src && T_src2key && invdepths && corr_out && mask_out,
+                "sweep_corr: NULL argument");
+    MVD_REQUIRE(N > 0 && h > 0 && w > 0 && hs > 0 && ws > 0 && S > 0, "sweep_corr: non-positive dimension");
+    MVD_REQUIRE(V >= 1 && V <= MVD_MAX_VIEWS, "sweep_corr: V=%d outside 1..%d", V, MVD_MAX_VIEWS);
+    MVD_REQUIRE(C % 64 == 0 && C >= 64 && C <= 512, "sweep_corr: C=%d must be a multiple of 64 in 64..512", C);
+    MVD_REQUIRE((long long)(hs + 3) * (ws + 3) * C < 0x7fffffffLL, "sweep_corr: source map %dx%dx%d too large", hs, ws, C);
+    MVD_REQUIRE(h <= 65535 && (long long)N * V <= 65535, "sweep_corr: h or N*V exceeds 65535");
+    const size_t lds = (size_t)2 * S * mvd::SWEEP_PX * sizeof(float);
+    MVD_REQUIRE(lds <= 160 * 1024, "sweep_corr: S=%d needs %zu B of LDS (> 160 KiB)", S, lds);
+    return MVD_OK;
+}
+
+int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, const float* K_key,
+                          const float* const* K_src, const float* const* T_src2key, const float* invdepths,
+                          int invdepth_mode, float corr_scale, int N, int C, int h, int w, int hs, int ws, int S, int V,
+                          float* const* corr_out, float* const* mask_out, void* workspace, size_t workspace_bytes,
+                          mvd_stream_t stream) {
+    int rc = sweep_corr_check(feat_key, feat_src, K_key, K_src, T_src2key, invdepths, invdepth_mode, N, C, h, w, hs, ws, S, V, corr_out, mask_out);
+    if (rc) return rc;
+    const size_t need = mvd_sweep_corr_workspace_bytes(N, C, h, w, hs, ws, V);
+    if (!workspace || workspace_bytes < need) {
+        mvd::set_error("sweep_corr: workspace %zu B < required %zu B", workspace_bytes, need);
+        return MVD_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* wsp = (float*)workspace;
+    rc = mvd::transpose_launch(feat_key, wsp, N, C, (long long)h * w, st);
+    if (rc) return rc;
+    const float* key = wsp;
+    wsp += mvd::align_up((size_t)N * C * h * w * sizeof(float), 256) / sizeof(float);
+    const size_t per = mvd::padded_slot_bytes_public(N, C, hs, ws) / sizeof(float);
+    const float* srcs[MVD_MAX_VIEWS];
+    for (int v = 0; v < V; ++v) {
+        MVD_REQUIRE(feat_src[v] && K_src[v] && T_src2key[v] && corr_out[v] && mask_out[v], "sweep_corr: NULL view %d", v);
+        rc = mvd::repack_padded_launch(feat_src[v], wsp + v * per, N, C, hs, ws, st);
+        if (rc) return rc;
+        srcs[v] = wsp + v * per;
+    }
+    return sweep_corr_run(key, srcs, K_key, K_src, T_src2key, invdepths, invdepth_mode, corr_scale, N, C, h, w, hs, ws, S, V, corr_out, mask_out, 0, st);
+}
+
+int mvd_sweep_corr_nhwc_f32(const float* feat_key, const float* const* feat_src, const float* K_key, const float* const* K_src,
+                            const float* const* T_src2key, const float* invdepths, int invdepth_mode, float corr_scale, int N, int C,
+                            int h, int w, int hs, int ws, int S, int V, float* const* corr_out, float* const* mask_out,
+                            int out_pixel_stride, mvd_stream_t stream) {
+    int rc = sweep_corr_check(feat_key, feat_src, K_key, K_src, T_src2key, invdepths, invdepth_mode, N, C, h, w, hs, ws, S, V, corr_out, mask_out);
+    if (rc) return rc;
+    MVD_REQUIRE(out_pixel_stride >= S, "sweep_corr_nhwc: output pixel stride %d below S=%d", out_pixel_stride, S);
+    for (int v = 0; v < V; ++v)
+        MVD_REQUIRE(feat_src[v] && K_src[v] && T_src2key[v] && corr_out[v] && mask_out[v], "sweep_corr: NULL view %d", v);
+    return sweep_corr_run(feat_key, feat_src, K_key, K_src, T_src2key, invdepths, invdepth_mode, corr_scale, N, C, h, w, hs, ws, S, V, corr_out,
+                          mask_out, out_pixel_stride, (hipStream_t)stream);
 }
 int mvd_sweep_warp_f32(const float* const* feat_src, const float* K_key, const float* const* K_src,
                        const float* const* T_src2key, const float* invdepths, int invdepth_mode, int normalize_after, int N,

@@ -52,14 +52,19 @@ def _upscale_to_multiple(images, intrinsics, m, device):
 
 
 class RobustMVD(nn.Module):
-    def __init__(self, half_dispnet=False):
-        """half_dispnet (an extension; the reference has no such switch; SURVEY.md 8f rank 1 names fp16 as a tuning lever
+    def __init__(self, half_dispnet=False, engine_dispnet=True):
+        """engine_dispnet (default on): at inference on the GPU in fp32 the whole 2-D CNN around the sweep runs on the engine's
+        split-operand convolution kernels, channel-last from the first layer to the prediction heads (dispnet_engine.py);
+        False: the reference's layer-by-layer form on the vendor library's convolutions.
+        half_dispnet (an extension; the reference has no such switch; SURVEY.md 8f rank 1 names fp16 as a tuning lever
         of the DispNet row): at inference the 2-D convolutions around the sweep — encoder, context encoder, fusion score
         convs, cost-volume encoder, decoder — run under torch.autocast(float16) on the vendor library's fp16 kernels
         (fp32 accumulation); the sweep (K1), the fusion arithmetic (K2) and the prediction heads' final arithmetic stay
         fp32.  Default False = fp32 everywhere, like the reference."""
         super().__init__()
         self.half_dispnet = bool(half_dispnet)
+        self.engine_dispnet = bool(engine_dispnet)
+        self._engine = None
         self.encoder = DispnetEncoder()
         self.context_encoder = DispnetContextEncoder()
         self.corr_block = PlanesweepCorrelation()
@@ -102,6 +107,13 @@ class RobustMVD(nn.Module):
 
         n = image_key.shape[0]
         same = all(im.shape == image_key.shape for im in images_source)
+        if (self.engine_dispnet and same and image_key.is_cuda and image_key.dtype == torch.float32 and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled() and image_key.shape[-2] % 64 == 0 and image_key.shape[-1] % 64 == 0):
+            if self._engine is None:
+                from .dispnet_engine import DispnetEngine
+                self._engine = DispnetEngine(self)
+            dec = self._engine.forward(image_key, images_source, intrinsics_key, intrinsics_source, source_to_key)
+            return self._outputs(dec)
         if same:  # one encoder pass over key + all sources
             feats = self.encoder.conv3(self.encoder.conv2(self.encoder.conv1(torch.cat(images_source, 0))))
             enc_sources = list(torch.split(feats, n, 0))
@@ -117,7 +129,10 @@ class RobustMVD(nn.Module):
         fused_corr, _ = self.fusion_block(corrs=corrs, masks=masks)
         all_enc_fused, enc_fused = self.fusion_enc_block(corr=fused_corr, ctx=ctx)
         dec = self.decoder(enc_fused=enc_fused, all_enc={**all_enc_key, **all_enc_fused})
+        return self._outputs(dec)
 
+    @staticmethod
+    def _outputs(dec):
         inv, log_b = dec["invdepth"].float(), dec["invdepth_log_b"].float()
         pred = {"depth": 1 / (inv + 1e-9), "depth_uncertainty": torch.exp(log_b) / (inv + 1e-9)}
         aux = dec

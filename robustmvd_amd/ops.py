@@ -546,26 +546,31 @@ def pack_conv2d_weights_split(weight, bias=None, stride=1, mode=L.CONV2D, cin_pa
     return SplitConv2dWeights(packed, b, cin, cin_pad, cout, kh, kw, stride, mode)
 
 
-def _nhwc_slice(t, name, channels=None):
-    """(B,H,W,C) fp32 device view whose pixels are `stride(2)` floats apart and dense otherwise -> (B,H,W,C, pixel stride)."""
+def _nhwc_slice(t, name, channels=None, free_rows=False):
+    """(B,H,W,C) fp32 device view with unit channel stride -> (B,H,W,C, pixel stride, row stride, image stride) in floats.  Without
+    free_rows the view must be a channel slice of a dense NHWC buffer (rows and images follow each other)."""
     if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
         raise ValueError(f"{name} must be a float32 device tensor (B,H,W,C)")
     B, H, W, C = t.shape
-    ps = t.stride(2) if W > 1 or H > 1 or B > 1 else max(C, 1)
-    if t.stride(3) != 1 or (W > 1 and t.stride(2) < C) or (H > 1 and t.stride(1) != W * ps) or (B > 1 and t.stride(0) != H * W * ps):
-        raise ValueError(f"{name}: a channel slice of a dense NHWC buffer is needed, got shape {tuple(t.shape)} strides {t.stride()}")
+    ps = t.stride(2) if W > 1 else max(C, 1)
+    rs = t.stride(1) if H > 1 else W * ps
+    ims = t.stride(0) if B > 1 else H * rs
+    if (C > 1 and t.stride(3) != 1) or ps < C or rs < W * ps or ims < H * rs:
+        raise ValueError(f"{name}: a channel slice of a channel-last buffer is needed, got shape {tuple(t.shape)} strides {t.stride()}")
+    if not free_rows and (rs != W * ps or ims != H * rs):
+        raise ValueError(f"{name}: a channel slice of a DENSE channel-last buffer is needed, got shape {tuple(t.shape)} strides {t.stride()}")
     if channels is not None and C != channels:
         raise ValueError(f"{name}: {C} channels, the layer takes {channels}")
-    return B, H, W, C, ps
+    return B, H, W, C, ps, rs, ims
 
 
 @inference_only
-def conv2d_split(x, x_absmax, wts, act=1, slope=0.2, out=None, out_absmax=None, use_workspace=True):
+def conv2d_split(x, x_absmax, wts, act=1, slope=0.2, out=None, out_absmax=None, use_workspace=True, planar_out=False):
     """One layer of Path A's 2-D CNN on the split-operand kernel (mvd_conv2d_split_f32).  x: (B,Hi,Wi,Cin_pad) NHWC fp32, possibly
     a channel slice of a wider buffer (mode CONV2D_IMAGE: the planar (B,3,Hi,Wi) image); x_absmax: one-element device tensor with
-    max |x|; wts: SplitConv2dWeights.  out: NHWC destination view (B,Ho,Wo,Cout), e.g. a slice of a concat buffer (allocated if
-    None); out_absmax: one-element device tensor that receives max |out| by atomic maximum (zero it first), or None.
-    act 0 none / 1 LeakyReLU(slope) / 2 ReLU.  Returns out."""
+    max |x|; wts: SplitConv2dWeights.  out: NHWC destination view (B,Ho,Wo,Cout), e.g. a slice of a concat buffer or the interior
+    of a zero-bordered map (allocated if None); planar_out: allocate and return (B,Cout,Ho,Wo) instead.  out_absmax: one-element
+    device tensor that receives max |out| by atomic maximum (zero it first), or None.  act 0 none / 1 LeakyReLU(slope) / 2 ReLU."""
     lib = L.load()
     if wts.mode == L.CONV2D_IMAGE:
         xi = L.as_f32(x, "x")
@@ -574,29 +579,119 @@ def conv2d_split(x, x_absmax, wts, act=1, slope=0.2, out=None, out_absmax=None, 
         B, _, Hi, Wi = xi.shape
         x, xs = xi, 0
     else:
-        B, Hi, Wi, _, xs = _nhwc_slice(x, "x", wts.cin_pad)
+        B, Hi, Wi, _, xs, _, _ = _nhwc_slice(x, "x", wts.cin_pad)
     if wts.mode == L.DECONV2D:
         Ho, Wo = 2 * Hi, 2 * Wi
     else:
         Ho = (Hi + 2 * (wts.kh // 2) - wts.kh) // wts.stride + 1
         Wo = (Wi + 2 * (wts.kw // 2) - wts.kw) // wts.stride + 1
     dev = x.device
-    if out is None:
-        out = torch.empty((B, Ho, Wo, wts.cout), dtype=torch.float32, device=dev)
-    ob, oh, ow, _, ys = _nhwc_slice(out, "out", wts.cout)
-    if (ob, oh, ow) != (B, Ho, Wo):
-        raise ValueError(f"out is {tuple(out.shape)}, the layer writes ({B},{Ho},{Wo},{wts.cout})")
+    if planar_out:
+        if out is not None:
+            raise ValueError("planar_out allocates its own output")
+        out = torch.empty((B, wts.cout, Ho, Wo), dtype=torch.float32, device=dev)
+        ys, rs, ims, cs = 1, Wo, wts.cout * Ho * Wo, Ho * Wo
+    else:
+        if out is None:
+            out = torch.empty((B, Ho, Wo, wts.cout), dtype=torch.float32, device=dev)
+        ob, oh, ow, _, ys, rs, ims = _nhwc_slice(out, "out", wts.cout, free_rows=True)
+        cs = 1
+        if (ob, oh, ow) != (B, Ho, Wo):
+            raise ValueError(f"out is {tuple(out.shape)}, the layer writes ({B},{Ho},{Wo},{wts.cout})")
     xam = L.as_f32(x_absmax, "x_absmax", (1,), dev)
     yam = None if out_absmax is None else L.as_f32(out_absmax, "out_absmax", (1,), dev)
     wsb = lib.mvd_conv2d_split_workspace_bytes(B, Hi, Wi, wts.cin_pad, wts.cout, wts.kh, wts.kw, wts.stride, wts.mode) if use_workspace else 0
-    if wsb > (64 << 20):  # only layers with few pixels split the reduction
-        wsb = 0
     wsp = _workspace(wsb, dev) if wsb else None
     with torch.cuda.device(dev):
         rc = lib.mvd_conv2d_split_f32(L.ptr(x), L.ptr(xam), L.ptr(wts.packed), L.ptr(wts.bias), L.ptr(out), L.ptr(yam), B, Hi, Wi,
-                                      wts.cin_pad, xs, wts.cout, ys, wts.kh, wts.kw, wts.stride, wts.mode, int(act), float(slope),
-                                      L.ptr(wsp), wsb, L.stream_of(x))
+                                      wts.cin_pad, xs, wts.cout, ys, rs, ims, cs, wts.kh, wts.kw, wts.stride, wts.mode, int(act),
+                                      float(slope), L.ptr(wsp), wsb, L.stream_of(x))
     L.check(rc, "mvd_conv2d_split_f32")
+    return out
+
+
+@inference_only
+def upsample2x_into(x, out, out_absmax=None):
+    """F.interpolate(x, size=(2h,2w), mode="bilinear", align_corners=False) of a planar (B,C,h,w) map written into the channel-last
+    slice out (B,2h,2w,C) (mvd_upsample2x_nhwc_f32: the decoder's up-sampled prediction inside the next level's concat buffer)."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    B, C, h, w = x.shape
+    ob, oh, ow, _, ys, _, _ = _nhwc_slice(out, "out", C)
+    if (ob, oh, ow) != (B, 2 * h, 2 * w):
+        raise ValueError(f"out is {tuple(out.shape)}, expected ({B},{2 * h},{2 * w},{C})")
+    yam = None if out_absmax is None else L.as_f32(out_absmax, "out_absmax", (1,), x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mvd_upsample2x_nhwc_f32(L.ptr(x), L.ptr(out), L.ptr(yam), B, C, h, w, ys, L.stream_of(x))
+    L.check(rc, "mvd_upsample2x_nhwc_f32")
+    return out
+
+
+@inference_only
+def sweep_corr_nhwc(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths, corrs, masks, corr_scale=None):
+    """K1 on its working layouts (mvd_sweep_corr_nhwc_f32): feat_key (N,h,w,C) channel-last; feat_sources V x zero-bordered
+    channel-last (N,hs+3,ws+3,C); corrs, masks: V x pixel-major destinations (N,h,w,S) (channel slices allowed), filled in place."""
+    lib = L.load()
+    fk = L.as_f32(feat_key, "feat_key")
+    N, h, w, C = fk.shape
+    dev = fk.device
+    srcs = _views(feat_sources, "feat_sources")
+    V = len(srcs)
+    hs, ws = srcs[0].shape[1] - 3, srcs[0].shape[2] - 3
+    srcs = [L.as_f32(s, f"feat_sources[{i}]", (N, hs + 3, ws + 3, C), dev) for i, s in enumerate(srcs)]
+    Kk = L.as_f32(K_key, "intrinsics_key", (N, 3, 3), dev)
+    Ks = [L.as_f32(k, f"intrinsics_sources[{i}]", (N, 3, 3), dev) for i, k in enumerate(_views(K_sources, "intrinsics_sources", V))]
+    Ts = [L.as_f32(t, f"source_to_key_transforms[{i}]", (N, 4, 4), dev) for i, t in enumerate(_views(T_src2key, "source_to_key_transforms", V))]
+    inv = L.as_f32(invdepths, "sampling_invdepths", device=dev)
+    mode = _invdepth_mode(inv, N, h, w)
+    S = inv.shape[1]
+    if C % 64 != 0:
+        raise ValueError(f"feature channels C={C} must be a multiple of 64")
+    ps = None
+    for name, ts in (("corrs", corrs), ("masks", masks)):
+        if len(ts) != V:
+            raise ValueError(f"{name}: {len(ts)} entries for {V} views")
+        for t in ts:
+            b_, h_, w_, _, p_, _, _ = _nhwc_slice(t, name, S)
+            if (b_, h_, w_) != (N, h, w) or (ps is not None and p_ != ps):
+                raise ValueError(f"{name}: (N,h,w,S) = ({N},{h},{w},{S}) maps with one common pixel stride are needed")
+            ps = p_
+    scale = float(corr_scale) if corr_scale is not None else 1.0 / float(C) ** 0.5
+    a_src, k1 = L.ptr_array(srcs)
+    a_K, k2 = L.ptr_array(Ks)
+    a_T, k3 = L.ptr_array(Ts)
+    a_c, k4 = L.ptr_array(list(corrs))
+    a_m, k5 = L.ptr_array(list(masks))
+    with torch.cuda.device(dev):
+        rc = lib.mvd_sweep_corr_nhwc_f32(L.ptr(fk), a_src, L.ptr(Kk), a_K, a_T, L.ptr(inv), mode, scale, N, C, h, w, hs, ws, S, V,
+                                         a_c, a_m, ps, L.stream_of(fk))
+    L.check(rc, "mvd_sweep_corr_nhwc_f32")
+    return corrs, masks
+
+
+@inference_only
+def fuse_views_nhwc(corrs, masks, scores, out, out_absmax=None):
+    """K2 on pixel-major volumes: corrs, masks V x (N,h,w,S); scores V x (N,h,w,1) or (N,1,h,w); out: (N,h,w,S) destination view
+    (a channel slice of the cost-volume encoder's input buffer).  Returns out."""
+    lib = L.load()
+    V = len(corrs)
+    N, h, w, S, ps, _, _ = _nhwc_slice(corrs[0], "corrs[0]")
+    dev = corrs[0].device
+    for name, ts in (("corrs", corrs), ("masks", masks)):
+        for t in ts:
+            if _nhwc_slice(t, name, S)[:5] != (N, h, w, S, ps):
+                raise ValueError(f"{name}: equal (N,h,w,S) maps are needed")
+    scores = [L.as_f32(s_.reshape(N, h * w), f"scores[{i}]", (N, h * w), dev) for i, s_ in enumerate(_views(scores, "scores", V))]
+    ob, oh, ow, _, ops_, _, _ = _nhwc_slice(out, "out", S)
+    if (ob, oh, ow) != (N, h, w):
+        raise ValueError(f"out is {tuple(out.shape)}, expected ({N},{h},{w},{S})")
+    yam = None if out_absmax is None else L.as_f32(out_absmax, "out_absmax", (1,), dev)
+    a_c, k1 = L.ptr_array(list(corrs))
+    a_m, k2 = L.ptr_array(list(masks))
+    a_s, k3 = L.ptr_array(scores)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_fuse_views_nhwc_f32(a_c, a_m, a_s, N, S, h, w, V, ps, L.ptr(out), None, ops_, L.ptr(yam), L.stream_of(corrs[0]))
+    L.check(rc, "mvd_fuse_views_nhwc_f32")
     return out
 
 

@@ -123,3 +123,60 @@ def test_conv2d_split_is_deterministic_and_refuses_bad_arguments(dev):
         ops.conv2d_split(x[..., :64], am, wts)
     with pytest.raises(ValueError, match="slice"):
         ops.conv2d_split(x.permute(0, 2, 1, 3), am, wts)
+
+
+def test_upsample2x_into_matches_torch_interpolate(dev):
+    from robustmvd_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 2, 7, 11, generator=g).to(dev)
+    buf = torch.full((2, 14, 22, 12), 5.0, device=dev)
+    am = torch.zeros(1, device=dev)
+    ops.upsample2x_into(x, buf[..., 8:10], out_absmax=am)
+    want = F.interpolate(x, size=(14, 22), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    # torch's formula and operation order; its GPU kernel contracts the blends into FMAs, this library does not: last-bit differences
+    torch.testing.assert_close(buf[..., 8:10], want, atol=1e-6, rtol=1e-6)
+    want_cpu = F.interpolate(x.cpu(), size=(14, 22), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    torch.testing.assert_close(buf[..., 8:10].cpu(), want_cpu, atol=1e-6, rtol=1e-6)
+    assert float(am) == float(buf[..., 8:10].abs().max())
+    assert float(buf[..., :8].min()) == 5.0 and float(buf[..., 10:].min()) == 5.0
+
+
+@pytest.mark.parametrize("V", [2, 4])
+def test_sweep_and_fusion_on_channel_last_layouts_equal_the_planar_entry_points(V, dev):
+    """mvd_sweep_corr_nhwc_f32 / mvd_fuse_views_nhwc_f32: the same kernels' arithmetic on the layouts the 2-D engine works in ->
+    bit-identical values, transposed."""
+    from robustmvd_amd import ops
+    import gen_common as gc
+    from oracle import mvd_oracle as O
+    N, C, h, w, S = 2, 64, 12, 20, 32
+    rng = np.random.default_rng(V)
+    fk = rng.standard_normal((N, C, h, w)).astype(np.float32)
+    srcs = [rng.standard_normal((N, C, h, w)).astype(np.float32) for _ in range(V)]
+    Kk = np.stack([np.array([[0.72, 0, 0.5], [0, 1.28, 0.5], [0, 0, 1]], np.float32)] * N)
+    Ks = [Kk * np.array([[1.0 + 0.05 * v], [1.0 - 0.03 * v], [1.0]], np.float32) for v in range(V)]
+    Ts = [np.stack([gc.synthetic_pose(rng, 0.08, 0.2) for _ in range(N)]) for _ in range(V)]
+    inv = O.compute_sampling_invdepths(np.full(1, 0.4, np.float32), np.full(1, 100.0, np.float32), S)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fk_t, srcs_t = t(fk), [t(s_) for s_ in srcs]
+    args = (t(Kk), [t(k) for k in Ks], [t(x) for x in Ts], t(inv))
+    corrs, masks = ops.sweep_corr(fk_t, srcs_t, *args)
+    key_cl = fk_t.permute(0, 2, 3, 1).contiguous()
+    bordered = []
+    for s_ in srcs_t:
+        b = torch.zeros(N, h + 3, w + 3, C, device=dev)
+        b[:, 1:h + 1, 1:w + 1] = s_.permute(0, 2, 3, 1)
+        bordered.append(b)
+    big_c, big_m = torch.zeros(V, N, h, w, S + 8, device=dev), torch.zeros(V, N, h, w, S + 8, device=dev)
+    c2 = [big_c[v, ..., 8:] for v in range(V)]
+    m2 = [big_m[v, ..., 8:] for v in range(V)]
+    ops.sweep_corr_nhwc(key_cl, bordered, *args, c2, m2)
+    for v in range(V):
+        assert torch.equal(c2[v].permute(0, 3, 1, 2), corrs[v]) and torch.equal(m2[v].permute(0, 3, 1, 2), masks[v])
+    scores = [torch.randn(N, 1, h, w, device=dev) for _ in range(V)]
+    fused, _ = ops.fuse_views(corrs, masks, scores)
+    out = torch.full((N, h, w, S + 4), 9.0, device=dev)
+    am = torch.zeros(1, device=dev)
+    ops.fuse_views_nhwc(c2, m2, scores, out[..., 4:], out_absmax=am)
+    assert torch.equal(out[..., 4:].permute(0, 3, 1, 2), fused)
+    assert float(am) == float(fused.abs().max()) and float(out[..., :4].min()) == 9.0

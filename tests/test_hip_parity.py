@@ -203,8 +203,9 @@ def test_robustmvd_end_to_end_golden(dev):
                   poses=[np.eye(4, dtype=np.float32), g["T0"]], keyview_idx=0)
     pred, aux = model.run(**sample)
     assert pred["depth"].shape == (1, 192, 288)
-    # Path A's final prediction in inverse-depth space at atol 1e-4.  The 2-D convolutions run on the vendor
-    # library (Winograd / implicit GEMM) here and on oneDNN in the reference; measured difference 2e-6 (tools/path_a_parity.py)
+    assert model.engine_dispnet and model._engine is not None and model._engine.w is not None  # the engine's 2-D CNN ran
+    # Path A's final prediction in inverse-depth space at atol 1e-4.  The 2-D convolutions run on the engine's
+    # split-operand kernels here (fp32-grade: tests/test_hip_conv2d_split.py) and on oneDNN in the reference
     np.testing.assert_allclose(aux["invdepth"], g["invdepth"], atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(aux["invdepths_all"][0], g["invdepths_all_0"], atol=1e-4, rtol=1e-4)
@@ -222,8 +223,22 @@ def test_robustmvd_two_sources_golden(dev):
     K2 = gc.synthetic_intrinsics(H2, W2)
     poses = [gc.synthetic_pose(rng), np.eye(4, dtype=np.float32), gc.synthetic_pose(rng)]
     pred, aux = model.run(images=images, intrinsics=[K2, K2, K2], poses=poses, keyview_idx=1)
+    assert model._engine is not None
     np.testing.assert_allclose(aux["invdepth"], g["invdepth"], atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(aux["invdepth_log_b"], g["invdepth_log_b"], atol=1e-4, rtol=1e-4)
+    # the layer-by-layer form on the vendor library's convolutions (engine_dispnet=False) against the same golden output
+    import robustmvd_amd as R
+    lib_model = R.RobustMVD(engine_dispnet=False).eval().to(dev)
+    lib_model.load_state_dict(model.state_dict())
+    pred_l, aux_l = lib_model.run(images=images, intrinsics=[K2, K2, K2], poses=poses, keyview_idx=1)
+    assert lib_model._engine is None
+    np.testing.assert_allclose(aux_l["invdepth"], g["invdepth"], atol=1e-4, rtol=1e-4)
+    for k in ("invdepth", "invdepth_log_b", "invdepth_uncertainty"):
+        np.testing.assert_allclose(aux[k], aux_l[k], atol=2e-5, rtol=2e-5)
+    assert len(aux["invdepths_all"]) == len(aux_l["invdepths_all"]) == 6
+    for a_, b_ in zip(aux["invdepths_all"], aux_l["invdepths_all"]):
+        assert a_.shape == b_.shape
+        np.testing.assert_allclose(a_, b_, atol=5e-5, rtol=5e-5)
 
 
 def test_dispnet_conv_epilogue_is_bit_identical_to_torch(dev):
