@@ -58,9 +58,9 @@ def build_mvsnet(D, dev, seed=0, half_features=False, conv0_split=True, exact_gr
     return R.add_run_function(model.to(dev)), sd
 
 
-def build_robustmvd(dev, seed=0, half_dispnet=False):
+def build_robustmvd(dev, seed=0, half_dispnet=False, engine_dispnet=True):
     import robustmvd_amd as R
-    model = R.RobustMVD(half_dispnet=half_dispnet).eval()
+    model = R.RobustMVD(half_dispnet=half_dispnet, engine_dispnet=engine_dispnet).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = gc.robustmvd_weights(shapes, seed)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -496,12 +496,25 @@ def main(argv=None):
         k1_flops = V * 256 * hs * ws_ * 256 * 10  # direct form: V*S*h*w*C*(2+8), SURVEY.md 8(d)
         out["path_a"] = {"model": "robust_mvd", "value": world * args.steps / dta, "unit": "depth-maps/sec",
                          "ms_per_step": dta / args.steps * 1e3, "sweep_corr_ms": k1_ms,
+                         "convolutions": "engine (mvd_conv2d_split_f32: fp32 operands split into 2 fp16 terms, 3 products on fp16 MFMA, "
+                                         "fp32 accumulate; channel-last, concat buffers written in place)",
                          "roofline": {"bound": "valu", "kernel": "sweep_corr (K1)", "achieved": k1_flops / (k1_ms * 1e-3) / 1e12,
                                       "peak": 157.3, "unit": "TFLOP/s", "frac": k1_flops / (k1_ms * 1e-3) / 1e12 / 157.3,
                                       "algorithmic_flops_per_launch": k1_flops, "algorithmic_bytes_per_launch": k1_bytes,
                                       "algorithmic_gbs": k1_bytes / (k1_ms * 1e-3) / 1e9, "avg_launch_ms": k1_ms,
                                       "launches_timed": args.steps, "pmc": k1_pmc}}
-        del ma
+        # the same model with its 2-D CNN layer by layer on the vendor library's convolutions (engine_dispnet=False: the round-2 form)
+        mv, _ = build_robustmvd(dev, engine_dispnet=False)
+        with torch.no_grad():
+            d0 = ma(**sa[0])[0]["depth"].clone()
+            d1 = mv(**sa[0])[0]["depth"].clone()
+        torch.cuda.synchronize(dev)
+        dtv = timed_loop(mv, sa, args.steps, args.warmup, world, dev, None, cdev)
+        out["path_a_vendor_convs"] = {"model": "robust_mvd(engine_dispnet=False)", "value": world * args.steps / dtv, "unit": "depth-maps/sec",
+                                      "ms_per_step": dtv / args.steps * 1e3,
+                                      "max_rel_depth_diff_vs_path_a": float(((d1 - d0).abs() / d0.abs()).max()),
+                                      "note": "MIOpen / rocBLAS convolutions + fused bias/LeakyReLU pass; not the default"}
+        del ma, mv
         torch.cuda.empty_cache()
         # opt-in variant, NOT the fp32 drop-in: the DispNet's 2-D convolutions on the vendor library's fp16 kernels under
         # autocast (SURVEY.md 8f rank 1 lists fp16 as a tuning lever of that row); sweep, fusion and heads stay fp32

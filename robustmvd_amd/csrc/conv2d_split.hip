@@ -28,6 +28,12 @@
 #include "mvd_common.h"
 #include <algorithm>
 
+// knock-out builds for tools/ko_conv2d.sh (timing only, WRONG results): 1 stage only a workgroup's first chunk, 2 no MFMAs,
+// 4 weights loaded once, 8 activation fragments read once per step, 16 no stores
+#ifndef C2_KO
+#define C2_KO 0
+#endif
+
 namespace mvd {
 
 typedef _Float16 c2h8 __attribute__((ext_vector_type(8)));
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
 
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         // ---- stage the chunk's patch: global fp32 -> two fp16 terms -> LDS -------------------------------------------------------
-        {
+        if (!(C2_KO & 1) || chunk == c_begin) {
             c2f4 v0[G::NIT], v1[G::NIT];
 #pragma unroll
             for (int k = 0; k < G::NIT; ++k) {
@@ -264,7 +270,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             c2h8 nh[NTW], nl[NTW];
-            {
+            if (C2_KO & 4) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) { nh[t] = wh[t]; nl[t] = wl[t]; }
+            } else {
                 const char* wn = wc + 2048;
                 wn = wn > wlast ? wlast : wn;
 #pragma unroll
@@ -279,12 +288,16 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const c2h8 ch = xh, cl = xl;
-                if (m + 1 < MTW) {
+                if (m + 1 < MTW && !(C2_KO & 8)) {
                     xh = *reinterpret_cast<const c2h8*>(a + (m + 1) * G::ROWB);
                     xl = *reinterpret_cast<const c2h8*>(a + (m + 1) * G::ROWB + PLANE);
                 }
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
+                    if (C2_KO & 2) {
+                        acc[m][t][0] += (float)ch[0] * (float)wh[t][0] + (float)cl[1] * (float)wl[t][1];
+                        continue;
+                    }
                     acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], ch, acc[m][t], 0, 0, 0);
                     acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], ch, acc[m][t], 0, 0, 0);
                     acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], cl, acc[m][t], 0, 0, 0);
@@ -313,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
                 }
             continue;
         }
-        if (cb >= p.Cout) continue;
+        if (cb >= p.Cout || ((C2_KO & 16) && p.B > 1000)) continue;
         const c2f4 eu = *reinterpret_cast<const c2f4*>(p.eun + cb);
         float bs[4];
 #pragma unroll
@@ -371,9 +384,23 @@ __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
         const int cls = (int)(i / (npix * c4n));
         const long long pl = (i / c4n) % npix;
         const int cb = (int)(i % c4n) * 4;
+        // ksplit is a power of two >= 2: eight loads in flight, added in the fixed order ks = 0, 1, ...
+        const float* pp = p.part + ((size_t)cls * p.ksplit * npix + pl) * p.ncp + cb;
+        const size_t kstr = (size_t)npix * p.ncp;
         c2f4 s = c2f4{0, 0, 0, 0};
-        for (int ks = 0; ks < p.ksplit; ++ks)
-            s += *reinterpret_cast<const c2f4*>(p.part + (((size_t)cls * p.ksplit + ks) * npix + pl) * p.ncp + cb);
+        int ks = 0;
+        for (; ks + 8 <= p.ksplit; ks += 8) {
+            c2f4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const c2f4*>(pp + (size_t)(ks + q) * kstr);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; ks + 2 <= p.ksplit; ks += 2) {
+            const c2f4 v0 = *reinterpret_cast<const c2f4*>(pp + (size_t)ks * kstr), v1 = *reinterpret_cast<const c2f4*>(pp + (size_t)(ks + 1) * kstr);
+            s += v0;
+            s += v1;
+        }
         const int ox = (int)(pl % p.Wo), oy = (int)((pl / p.Wo) % p.Ho), b = (int)(pl / ((long long)p.Wo * p.Ho));
         float* dst = p.y + (size_t)b * p.ys_img + ((size_t)oy * p.oy_mul + (cls >> 1)) * p.ys_row + ((size_t)ox * p.ox_mul + (cls & 1)) * p.ys + cb * p.ycs;
         float r4[4];

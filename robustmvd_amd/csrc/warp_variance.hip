@@ -1243,10 +1243,16 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
     __shared__ float wmax[4];
     const long long n4 = n / 4, stride = (long long)gridDim.x * 256;
     float m = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
+    auto take = [&m](const float4 v) {
         m = fmaxf(fmaxf(m, fmaxf(finite_abs_or_zero(v.x), finite_abs_or_zero(v.y))), fmaxf(finite_abs_or_zero(v.z), finite_abs_or_zero(v.w)));
+    };
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {  // four loads in flight per thread
+        const float4 v0 = reinterpret_cast<const float4*>(x)[i], v1 = reinterpret_cast<const float4*>(x)[i + stride];
+        const float4 v2 = reinterpret_cast<const float4*>(x)[i + 2 * stride], v3 = reinterpret_cast<const float4*>(x)[i + 3 * stride];
+        take(v0); take(v1); take(v2); take(v3);
     }
+    for (; i < n4; i += stride) take(reinterpret_cast<const float4*>(x)[i]);
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) m = fmaxf(m, finite_abs_or_zero(x[n4 * 4 + threadIdx.x]));
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;

@@ -230,6 +230,7 @@ def test_robustmvd_two_sources_golden(dev):
     import robustmvd_amd as R
     lib_model = R.RobustMVD(engine_dispnet=False).eval().to(dev)
     lib_model.load_state_dict(model.state_dict())
+    R.add_run_function(lib_model)
     pred_l, aux_l = lib_model.run(images=images, intrinsics=[K2, K2, K2], poses=poses, keyview_idx=1)
     assert lib_model._engine is None
     np.testing.assert_allclose(aux_l["invdepth"], g["invdepth"], atol=1e-4, rtol=1e-4)
