@@ -39,10 +39,16 @@ namespace mvd {
 typedef _Float16 c2h8 __attribute__((ext_vector_type(8)));
 typedef float c2f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int c2u4 __attribute__((ext_vector_type(4)));
-
 constexpr int C2_TH = 16, C2_TW = 16;  // output pixels per workgroup tile
 
-template <int KH, int KW, int S, int U8>
+// buffer_load_dwordx4 ... lds: 16 bytes per lane from global memory straight into LDS at lds_dst + 16 * lane (no registers, counted
+// by vmcnt).  Inline asm for the reason csrc/warp_variance_tile.hip gives (the builtin makes every later LDS read wait for it);
+// M0 is written and not restored: nothing else in this translation unit uses it.
+__device__ __forceinline__ void c2_lds_dma_b128(c2u4 rsrc, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+
+template <int KH, int KW, int S, int U8, bool IMG = false>
 struct C2Geom {
     static constexpr int CC = 8 * U8;                          // input channels per staged chunk
     static constexpr int PB = CC * 2 + (U8 % 2 == 0 ? 16 : 0); // LDS bytes per pixel and term: PB / 16 odd = conflict-free rows
@@ -56,6 +62,21 @@ struct C2Geom {
     static constexpr int NIT = (ITEMS + 255) / 256;
     static_assert(2 * PLANE <= 80 * 1024, "patch exceeds half the LDS (two workgroups per CU)");
     static_assert((PB / 16) % 2 == 1, "pixel pitch must be an odd number of 16-byte slots");
+};
+// The first layer on a planar 3-channel image (7 x 7, stride 2): a pixel is 4 halves (r, g, b, 0) = 8 bytes, rows are stored as
+// they are (no parity planes), so the 16 bytes a lane reads are the TWO x-adjacent pixels of taps kx = 2g, 2g + 1 and a K step is
+// one kernel row: 7 x 4 = 28 real values of 32 (kx = 7 meets zero weights) in 7 steps, against 13 steps of 8-channel pixels.
+template <int KH, int KW, int S, int U8>
+struct C2Geom<KH, KW, S, U8, true> {
+    static_assert(KH == 7 && KW == 7 && S == 2 && U8 == 1, "image layer: 7 x 7, stride 2");
+    static constexpr int CC = 8, PB = 8;
+    static constexpr int PH = (C2_TH - 1) * S + KH, PW = (C2_TW - 1) * S + KW + 1;  // + the column tap kx = 7 reads
+    static constexpr int ROWB = S * PW * PB;
+    static constexpr int PLANE = PH * PW * PB;
+    static constexpr int STEPS = KH;
+    static constexpr int ITEMS = PH * PW;
+    static constexpr int NIT = (ITEMS + 255) / 256;
+    static_assert(PW % 2 == 0, "16-byte aligned pixel pairs");
 };
 
 struct C2Params {
@@ -77,6 +98,7 @@ struct C2Params {
     int tiles_x, tiles_y, nblocks, ksplit, chunks_per_split;
     int ncls;             // 1, or 4 = the output parity classes (a, b) of a transposed conv: pad - (a, b), output offset (a, b)
     long long cls_bytes;
+    unsigned x_bytes;     // bytes of the input tensor from x on (the bound of the prefetching kernels' buffer descriptor)
     int act;              // 0 none, 1 LeakyReLU(slope), 2 ReLU
     float slope;
 };
@@ -121,11 +143,16 @@ __global__ void c2_pack_kernel(const float* __restrict__ w, const float* __restr
     const int nt = (int)(r % ntiles);
     const int cls = (int)(r / ntiles);
     const int cout = nt * 16 + (lane & 15), unit = 4 * step + (lane >> 4);
-    const int tap = unit / U8, cin = chunk * 8 * U8 + 8 * (unit % U8) + j;
+    int tap = unit / U8, cin = chunk * 8 * U8 + 8 * (unit % U8) + j;
+    if (transposed == 2) {  // image layer: step = kernel row, lane group = the tap pair kx = 2g, 2g + 1, 4 halves per pixel
+        const int kx = 2 * (lane >> 4) + j / 4;
+        tap = kx < KW ? step * KW + kx : KH * KW;
+        cin = j % 4;
+    }
     float v = 0.f;
     if (tap < KH * KW && cin < Cin && cout < Cout) {
         const int ty = tap / KW, tx = tap % KW;
-        if (transposed) {
+        if (transposed == 1) {
             const int a = cls >> 1, b = cls & 1, ky = 3 - a - 2 * ty, kx = 3 - b - 2 * tx;
             v = w[(((size_t)cin * Cout + cout) * 4 + ky) * 4 + kx];
         } else {
@@ -139,10 +166,14 @@ __global__ void c2_pack_kernel(const float* __restrict__ w, const float* __restr
 
 template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
 __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
-    using G = C2Geom<KH, KW, S, U8>;
+    using G = C2Geom<KH, KW, S, U8, NCHW3>;
     constexpr int WN = 4 / WM, MTW = 16 / WM, STEPS = G::STEPS, PB = G::PB, PLANE = G::PLANE;
-    extern __shared__ __attribute__((aligned(16))) char patch[];  // [term][row][column parity][column / S][PB]
-    __shared__ float wmax[4];
+    // 8-channel chunks are short (3 .. 7 K steps): the next chunk's global reads go straight into a per-thread LDS scratch by
+    // LDS-DMA while this chunk's MFMAs run, so that only their conversion, not their latency, sits between two chunks
+    constexpr bool PF = U8 == 1 && !NCHW3;
+    constexpr int RAW0 = 2 * PLANE, RAWB = G::NIT * 4096, WMAX0 = RAW0 + (PF ? 2 * RAWB : 0);
+    extern __shared__ __attribute__((aligned(16))) char patch[];  // [term][row][column parity][column / S][PB] | scratch | 4 floats
+    float* const wmax = reinterpret_cast<float*>(patch + WMAX0);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int g = lane >> 4, px16 = lane & 15;
@@ -183,6 +214,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
 
     // staging items of this thread: global offset (floats, without the chunk's channel offset; -1 = outside the image) and LDS byte
     long long goff[G::NIT];
+    unsigned gvo[G::NIT];  // PF: byte offset from p.x (beyond the descriptor's bound = reads zeros)
     int loff[G::NIT];
 #pragma unroll
     for (int k = 0; k < G::NIT; ++k) {
@@ -192,19 +224,42 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
         const int iy = iy0 + py, ix = ix0 + pxx;
         const bool live = it < G::ITEMS;
         const bool inside = live && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-        if constexpr (NCHW3) goff[k] = inside ? ((long long)b * 3 * p.Hi + iy) * p.Wi + ix : -1;
-        else goff[k] = inside ? (((long long)b * p.Hi + iy) * p.Wi + ix) * p.xs + c8 * 8 : -1;
-        loff[k] = live ? ((py * S + pxx % S) * G::PWS + pxx / S) * PB + c8 * 16 : -1;
+        if constexpr (NCHW3) {
+            goff[k] = inside ? ((long long)b * 3 * p.Hi + iy) * p.Wi + ix : -1;
+            loff[k] = live ? pix * PB : -1;
+        } else {
+            goff[k] = inside ? (((long long)b * p.Hi + iy) * p.Wi + ix) * p.xs + c8 * 8 : -1;
+            loff[k] = live ? ((py * S + pxx % S) * G::PWS + pxx / S) * PB + c8 * 16 : -1;
+        }
+        gvo[k] = inside ? (unsigned)(goff[k] * 4) : 0xF0000000u;
     }
+    c2u4 rsrc;
+    if constexpr (PF) {
+        const unsigned long long xa = reinterpret_cast<unsigned long long>(p.x);
+        rsrc = c2u4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa),
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xa >> 32)) & 0xffffu, p.x_bytes, 0x00020000u};
+    }
+    const unsigned wv_lds = (unsigned)__builtin_amdgcn_readfirstlane(wv) * 1024u;  // the wave's 1 KB of each scratch row (scalar: goes to M0)
+    auto dma_chunk = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < G::NIT; ++k) {
+            c2_lds_dma_b128(rsrc, gvo[k] + (unsigned)chunk * 32u, (unsigned)(RAW0 + k * 4096) + wv_lds);
+            c2_lds_dma_b128(rsrc, gvo[k] + (unsigned)chunk * 32u + 16u, (unsigned)(RAW0 + RAWB + k * 4096) + wv_lds);
+        }
+    };
 
     // activation fragment address of this lane per K step (row 0 of the wave's rows)
     int tapoff[STEPS];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-        int unit = 4 * s + g;
-        if (unit >= G::UNITS) unit = 0;  // meets zero weights
-        const int tap = unit / U8, c8 = unit % U8, ky = tap / KW, kx = tap % KW;
-        tapoff[s] = ((ky * S + kx % S) * G::PWS + kx / S + px16) * PB + c8 * 16 + wm * MTW * G::ROWB;
+        if constexpr (NCHW3) {  // step = kernel row, lane group g = the tap pair kx = 2g, 2g + 1
+            tapoff[s] = (s * G::PW + 2 * px16 + 2 * g) * PB + wm * MTW * G::ROWB;
+        } else {
+            int unit = 4 * s + g;
+            if (unit >= G::UNITS) unit = 0;  // meets zero weights
+            const int tap = unit / U8, c8 = unit % U8, ky = tap / KW, kx = tap % KW;
+            tapoff[s] = ((ky * S + kx % S) * G::PWS + kx / S + px16) * PB + c8 * 16 + wm * MTW * G::ROWB;
+        }
     }
 
     // weights: this wave's cout tiles
@@ -232,9 +287,32 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
         }
     }
 
+    if constexpr (PF)
+        if (c_begin < c_end) dma_chunk(c_begin);
+
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         // ---- stage the chunk's patch: global fp32 -> two fp16 terms -> LDS -------------------------------------------------------
-        if (!(C2_KO & 1) || chunk == c_begin) {
+        if constexpr (PF) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's scratch has landed (and the weight fragments)
+            __syncthreads();                                  // every wave has finished reading the previous chunk's patch
+            if (!(C2_KO & 1) || chunk == c_begin) {
+#pragma unroll
+                for (int k = 0; k < G::NIT; ++k) {
+                    if (loff[k] < 0) continue;
+                    const c2f4 a0 = *reinterpret_cast<const c2f4*>(patch + RAW0 + (k * 256 + tid) * 16);
+                    const c2f4 a1 = *reinterpret_cast<const c2f4*>(patch + RAW0 + RAWB + (k * 256 + tid) * 16);
+                    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                    split2(a0[0], a0[1], h0, l0);
+                    split2(a0[2], a0[3], h1, l1);
+                    split2(a1[0], a1[1], h2, l2);
+                    split2(a1[2], a1[3], h3, l3);
+                    *reinterpret_cast<c2u4*>(patch + loff[k]) = c2u4{h0, h1, h2, h3};
+                    *reinterpret_cast<c2u4*>(patch + loff[k] + PLANE) = c2u4{l0, l1, l2, l3};
+                }
+            }
+            __syncthreads();
+            if (chunk + 1 < c_end && !(C2_KO & 1)) dma_chunk(chunk + 1);  // the thread has consumed its scratch: refill it under the MFMAs
+        } else if (!(C2_KO & 1) || chunk == c_begin) {
             c2f4 v0[G::NIT], v1[G::NIT];
 #pragma unroll
             for (int k = 0; k < G::NIT; ++k) {
@@ -258,6 +336,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
                 unsigned h0, h1, h2, h3, l0, l1, l2, l3;
                 split2(v0[k][0], v0[k][1], h0, l0);
                 split2(v0[k][2], v0[k][3], h1, l1);
+                if constexpr (NCHW3) {
+                    *reinterpret_cast<unsigned long long*>(patch + loff[k]) = (unsigned long long)h0 | ((unsigned long long)h1 << 32);
+                    *reinterpret_cast<unsigned long long*>(patch + loff[k] + PLANE) = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
+                    continue;
+                }
                 split2(v1[k][0], v1[k][1], h2, l2);
                 split2(v1[k][2], v1[k][3], h3, l3);
                 *reinterpret_cast<c2u4*>(patch + loff[k]) = c2u4{h0, h1, h2, h3};
@@ -484,6 +567,8 @@ static bool c2_shape(int KH, int KW, int stride, int mode, int cin_pad, C2Shape*
     } else if (mode == 2) {
         if (KH != 7 || KW != 7 || stride != 2 || cin_pad != 8) return false;
         s->U8 = 1;
+        s->steps = 7;
+        return true;
     } else if (KH == 1 && KW == 1 && stride == 1) {
         if (cin_pad % 32) return false;
         s->U8 = 4;
@@ -535,9 +620,11 @@ static C2Plan c2_plan(const C2Shape& s, int B, int Hi, int Wi, int cin_pad, int 
 
 template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
 static int c2_launch(const C2Params& p, long long nblk, hipStream_t st) {
-    using G = C2Geom<KH, KW, S, U8>;
+    using G = C2Geom<KH, KW, S, U8, NCHW3>;
     auto kern = conv2d_split_kernel<KH, KW, S, U8, WM, NTW, NCHW3>;
-    constexpr int lds = 2 * G::PLANE;
+    constexpr bool PF = U8 == 1 && !NCHW3;
+    constexpr int lds = 2 * G::PLANE + (PF ? 2 * G::NIT * 4096 : 0) + 16;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
     if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return launch_status("conv2d_split: LDS attribute");
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, p);
@@ -590,7 +677,7 @@ int mvd_pack_conv2d_weights_split(const float* w, int Cin, int Cin_pad, int Cout
     hipLaunchKernelGGL(mvd::c2_wscale_kernel, dim3(cpad), dim3(256), 0, st, w, eun, Cin, Cout, KH * KW, s.transposed ? 1 : 0, cpad);
     const long long total = (long long)(fb / 2);
     hipLaunchKernelGGL(mvd::c2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, eun, (_Float16*)packed, Cin, Cout, s.KH,
-                       s.KW, s.U8, Cin_pad / (8 * s.U8), mvd::c2_ntiles(Cout), s.steps, s.transposed ? 1 : 0, total);
+                       s.KW, s.U8, Cin_pad / (8 * s.U8), mvd::c2_ntiles(Cout), s.steps, s.transposed ? 1 : s.nchw3 ? 2 : 0, total);
     return mvd::launch_status("pack_conv2d_weights_split");
 }
 
@@ -621,6 +708,11 @@ int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* pack
     p.x = x; p.xamax = x_absmax; p.bias = bias; p.y = y; p.yamax = y_absmax;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.xs = x_pixel_stride; p.nchunks = Cin_pad / (8 * s.U8);
     p.Cout = Cout; p.ys = y_pixel_stride; p.act = act; p.slope = slope;
+    if (mode != 2) {
+        const long long xb = ((long long)B * Hi * Wi - 1) * x_pixel_stride * 4 + (long long)Cin_pad * 4;
+        MVD_REQUIRE(xb < 0x70000000LL, "conv2d_split: input of %lld bytes exceeds the 31-bit offset range", xb);
+        p.x_bytes = (unsigned)xb;
+    }
     const size_t fb = mvd::c2_frag_bytes(s, Cin_pad, Cout);
     p.eun = reinterpret_cast<const float*>(static_cast<const char*>(packed_w) + fb);
     const mvd::C2Plan q = mvd::c2_plan(s, B, Hi, Wi, Cin_pad, Cout, KH, KW, stride);
