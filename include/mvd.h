@@ -245,6 +245,23 @@ size_t mvd_conv3d_split_packed_weight_bytes(int Cin, int Cout);
 int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packed, mvd_stream_t stream);
 int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
                                  float* y, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
+/* The same, and max |y| over the finite outputs into *y_absmax (device, one float): a by-product of the store epilogue. */
+int mvd_conv3d_bn_relu_absmax_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
+                                        float* y, float* y_absmax, int B, int D, int h, int w, int Cin, int Cout, int relu,
+                                        mvd_stream_t stream);
+/* K4's stride-2 and transposed layers (and stride-1 layers with many channels) on the split-operand implicit-GEMM kernel of the
+ * 2-D engine (csrc/conv2d_split.hip: the depth taps are extra chunks of the reduction; a transposed 3x3x3 stride-2 layer runs as a
+ * 2x2x2 convolution with 8 Cout output channels = (parity class, channel)).  x (B,Di,Hi,Wi,Cin) channel-last fp32, Cin a multiple of 8
+ * (16 for the transposed form), Cout a multiple of 4; mode MVD_CONV3D_STRIDE1 / _STRIDE2 / MVD_DECONV3D_STRIDE2 with the output
+ * sizes of mvd_conv3d_bn_relu_f32; weights in Conv3d / ConvTranspose3d layout.  y = relu?(conv * scale + shift) (+ skip, laid out
+ * like y, may be NULL).  x_absmax as for mvd_conv3d_bn_relu_f32_split; y_absmax NULL or a device float that receives max |y|
+ * (set by this call).  workspace NULL or mvd_conv3d_igemm_workspace_bytes bytes (few-voxel layers split the reduction). */
+size_t mvd_conv3d_igemm_packed_weight_bytes(int Cin, int Cout, int mode);
+int mvd_pack_conv3d_weights_igemm(const float* w, int Cin, int Cout, int mode, void* packed, mvd_stream_t stream);
+size_t mvd_conv3d_igemm_workspace_bytes(int B, int Di, int Hi, int Wi, int Cin, int Cout, int mode);
+int mvd_conv3d_bn_relu_igemm_f32(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
+                                 const float* skip, float* y, float* y_absmax, int B, int Di, int Hi, int Wi, int Cin, int Cout, int mode,
+                                 int relu, void* workspace, size_t workspace_bytes, mvd_stream_t stream);
 /* ---- Path A's 2-D CNN: split-operand implicit-GEMM convolutions ------------------------------------------------------------
  * Replace torch.nn.functional.conv2d / conv_transpose2d + bias + LeakyReLU (+ torch.cat of the inputs) of the DispNet blocks of
  * robust_mvd (rmvd/models/blocks/dispnet_encoder.py:6-27, dispnet_context_encoder.py, learned_fusion.py:8-20,

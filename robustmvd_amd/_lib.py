@@ -72,6 +72,13 @@ SIGNATURES = {
     "mvd_conv3d_bn_relu_f16in": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 7
                                  + [ctypes.c_void_p]),
     "mvd_conv3d_split_packed_weight_bytes": (_sz, [_i, _i]),
+    "mvd_conv3d_bn_relu_absmax_f32_split": (_i, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p]
+                                            + [_i] * 7 + [ctypes.c_void_p]),
+    "mvd_conv3d_igemm_packed_weight_bytes": (_sz, [_i] * 3),
+    "mvd_pack_conv3d_weights_igemm": (_i, [_c_float_p, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]),
+    "mvd_conv3d_igemm_workspace_bytes": (_sz, [_i] * 7),
+    "mvd_conv3d_bn_relu_igemm_f32": (_i, [_c_float_p, _c_float_p, ctypes.c_void_p] + [_c_float_p] * 5 + [_i] * 8
+                                     + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "mvd_conv2d_split_packed_weight_bytes": (_sz, [_i] * 6),
     "mvd_pack_conv2d_weights_split": (_i, [_c_float_p] + [_i] * 7 + [ctypes.c_void_p, ctypes.c_void_p]),
     "mvd_conv2d_split_workspace_bytes": (_sz, [_i] * 9),

@@ -297,9 +297,12 @@ class CostRegNet(nn.Module):
         pk["prob"] = (w, 8, 1, torch.ones(1, device=w.device), self.prob.bias.detach().contiguous(), L.CONV3D_STRIDE1)
         # fp16-feature variant (BASELINE configs[3]): conv0's weights rounded to fp16 in fp16-MFMA fragment order
         pk["conv0_f16"] = ops.pack_conv3d_weights_f16(self.conv0.conv.weight.detach())
-        if self.conv0_split:  # the stride-1 layers with 16 or 32 input channels take the split-operand kernel
-            for name in ("conv0", "conv2", "conv4"):
-                pk[name + "_split"] = ops.pack_conv3d_weights_split(getattr(self, name).conv.weight.detach())
+        if self.conv0_split:  # split-operand kernels: conv0 on the plane-marching one, conv1 .. conv4 and conv6 on the implicit GEMM
+            pk["conv0_split"] = ops.pack_conv3d_weights_split(self.conv0.conv.weight.detach())
+            for name, _, _, stride in self.LAYERS:
+                if name in ("conv1", "conv2", "conv3", "conv4", "conv6"):
+                    pk[name + "_igemm"] = ops.pack_conv3d_weights_igemm(getattr(self, name).conv.weight.detach(),
+                                                                        L.CONV3D_STRIDE1 if stride == 1 else L.CONV3D_STRIDE2)
         self._packed, self._packed_key = pk, key
         return pk
 
@@ -319,24 +322,35 @@ class CostRegNet(nn.Module):
         if x.dtype == torch.float16:  # the fp16 volume of ops.warp_variance_f16: first layer on fp16 MFMA, fp32 out
             _, _, _, scale0, shift0, _ = pk["conv0"]
             conv0 = ops.conv3d_bn_relu_f16in(x, pk["conv0_f16"], scale0, shift0, relu=True)
+            a0 = None
         elif self.conv0_split:
             _, _, _, scale0, shift0, _ = pk["conv0"]
-            conv0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True, x_absmax=x_absmax)
+            # (max |conv0| by a pass of its own: as a by-product of the kernel's store epilogue it cost twice that, 58 us)
+            conv0, a0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True, x_absmax=x_absmax), None
         else:
             conv0 = layer("conv0", x)
-        def down_then_same(down, same, t):
-            """conv1 -> conv2 (16 -> 16) and conv3 -> conv4 (32 -> 32): the stride-1 layer on the split-operand kernel, scaled by
-            max |x| of its input, which the stride-2 layer before it leaves behind as a by-product of its store epilogue."""
-            if not self.conv0_split:
-                return layer(same, layer(down, t))
-            w, cin, cout, scale, shift, mode = pk[down]
-            t, amax = ops.conv3d_bn_relu(t, w, cin, cout, scale, shift, mode, relu=True, return_absmax=True)
-            _, _, _, sc, sh, _ = pk[same]
-            return ops.conv3d_bn_relu_split(t, pk[same + "_split"], sc, sh, relu=True, x_absmax=amax)
+        if self.conv0_split:
+            # conv1 .. conv6 on the split-operand kernels, each scaled by max |x| of its input, which the layer before leaves behind
+            # as a by-product of its store epilogue: conv1, conv3 (stride 2), conv2, conv4, conv6 (stride 1) on the implicit-GEMM
+            # kernel of the 2-D engine (depth taps as chunks), conv5 and the transposed layers on the fp32 matrix instruction
+            # (measured faster there: tools/bench_k4_igemm.py)
+            def ig(name, t, a, want_absmax=True):
+                _, cin, cout, sc, sh, mode = pk[name]
+                return ops.conv3d_bn_relu_igemm(t, a, pk[name + "_igemm"], cin, cout, sc, sh, mode, relu=True, return_absmax=want_absmax)
 
-        conv2 = down_then_same("conv1", "conv2", conv0)
-        conv4 = down_then_same("conv3", "conv4", conv2)
-        y = layer("conv6", layer("conv5", conv4))
+            if a0 is None:
+                a0 = ops.absmax(conv0)
+            t, a = ig("conv1", conv0, a0)
+            conv2, a = ig("conv2", t, a)
+            t, a = ig("conv3", conv2, a)
+            conv4, a = ig("conv4", t, a, want_absmax=False), None
+            w5, cin5, cout5, sc5, sh5, mode5 = pk["conv5"]
+            t, a = ops.conv3d_bn_relu(conv4, w5, cin5, cout5, sc5, sh5, mode5, relu=True, return_absmax=True)
+            y = ig("conv6", t, a, want_absmax=False)
+        else:
+            conv2 = layer("conv2", layer("conv1", conv0))
+            conv4 = layer("conv4", layer("conv3", conv2))
+            y = layer("conv6", layer("conv5", conv4))
         y = layer("conv7", y, skip=conv4)
         del conv4
         y = layer("conv9", y, skip=conv2)

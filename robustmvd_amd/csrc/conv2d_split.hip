@@ -41,13 +41,6 @@ typedef float c2f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int c2u4 __attribute__((ext_vector_type(4)));
 constexpr int C2_TH = 16, C2_TW = 16;  // output pixels per workgroup tile
 
-// buffer_load_dwordx4 ... lds: 16 bytes per lane from global memory straight into LDS at lds_dst + 16 * lane (no registers, counted
-// by vmcnt).  Inline asm for the reason csrc/warp_variance_tile.hip gives (the builtin makes every later LDS read wait for it);
-// M0 is written and not restored: nothing else in this translation unit uses it.
-__device__ __forceinline__ void c2_lds_dma_b128(c2u4 rsrc, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
-}
-
 template <int KH, int KW, int S, int U8, bool IMG = false>
 struct C2Geom {
     static constexpr int CC = 8 * U8;                          // input channels per staged chunk
@@ -84,11 +77,17 @@ struct C2Params {
     const float* xamax;   // max |x| (device, one float)
     const char* wpk;      // packed weight fragments (transposed conv: 4 parity classes, cls_bytes apart)
     const float* eun;     // per output channel 2^k_c (padded to a multiple of 16)
-    const float* bias;    // Cout or NULL
+    const float* bias;    // Cout or NULL (3-D layers: the folded batch-norm shift)
+    const float* scale;   // NULL, or the folded batch-norm scale per channel: y = act(conv * scale + bias)
+    const float* skip;    // NULL, or a tensor laid out like y that is added after the activation
     float* y;             // output, NHWC, first channel of the slice; pixel stride ys floats
     float* yamax;         // optional: max |y| over the finite outputs (atomicMax; zeroed by the caller)
     float* part;          // split-K: partial sums [ksplit][B Ho Wo][ncp]; NULL = direct epilogue
-    int B, Hi, Wi, xs, nchunks;
+    int B, Hi, Wi, xs, nchunks;   // B = output images of the launch: batch x output planes for a 3-D layer
+    // 3-D layers (a 2-D layer has Di = Do = KD = SD = 1, pad_d = 0): image b' = (b, od) reads input planes od * SD - pad_d + kd;
+    // chunk = kd * nchunks_c + c.  sub3d: a transposed 3 x 3 x 3 stride-2 layer run as a 2 x 2 x 2 convolution whose output channels
+    // are (parity class (ad, ay, ax), channel): class goes to output voxel (2 od + ad, 2 oy + ay, 2 ox + ax)
+    int Di, Do, Dy, KD, SD, pad_d, nchunks_c, sub3d, Cr;
     int Ho, Wo;           // output grid of this launch (transposed conv: one parity class = the input grid)
     int Hy, Wy, ys;       // the output tensor's full grid; floats between pixels
     long long ys_row, ys_img, ycs;  // floats between output rows, images and channels (ycs = 1: channel-last)
@@ -98,7 +97,6 @@ struct C2Params {
     int tiles_x, tiles_y, nblocks, ksplit, chunks_per_split;
     int ncls;             // 1, or 4 = the output parity classes (a, b) of a transposed conv: pad - (a, b), output offset (a, b)
     long long cls_bytes;
-    unsigned x_bytes;     // bytes of the input tensor from x on (the bound of the prefetching kernels' buffer descriptor)
     int act;              // 0 none, 1 LeakyReLU(slope), 2 ReLU
     float slope;
 };
@@ -164,16 +162,47 @@ __global__ void c2_pack_kernel(const float* __restrict__ w, const float* __restr
     packed[e] = term == 0 ? hi : (_Float16)(v - (float)hi);
 }
 
+// epilogue of 4 consecutive output channels cb .. cb + 3 of output pixel (oy, ox) of image bi (main kernel and split-K reduce)
+__device__ __forceinline__ void c2_finish(const C2Params& p, int bi, int oy, int ox, int cls, int cb, c2f4 a, float xsc_inv, float& amax) {
+    const int od = bi % p.Do, b = bi / p.Do;
+    int c = cb, zo = od, yo = oy * p.oy_mul + (cls >> 1), xo = ox * p.ox_mul + (cls & 1);
+    if (p.sub3d) {
+        const int k3 = cb / p.Cr;
+        c = cb - k3 * p.Cr;
+        zo = 2 * od + (k3 >> 2); yo = 2 * oy + ((k3 >> 1) & 1); xo = 2 * ox + (k3 & 1);
+    }
+    const size_t o = ((size_t)b * p.Dy + zo) * p.ys_img + (size_t)yo * p.ys_row + (size_t)xo * p.ys + (size_t)c * p.ycs;
+    float r4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
+        if (cb + r < p.Cout) {
+            const float conv = a[r] * (p.eun[cb + r] * xsc_inv);  // exact: powers of two
+            v = p.scale ? fmaf(conv, p.scale[c + r], p.bias[c + r]) : conv + (p.bias ? p.bias[c + r] : 0.f);
+            if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+            else if (p.act == 2) v = fmaxf(v, 0.f);
+            if (p.skip) v += p.skip[o + r * p.ycs];
+            amax = fmaxf(amax, finite_abs_or_zero(v));
+        }
+        r4[r] = v;
+    }
+    if (cb + 3 < p.Cout && p.ycs == 1) {
+        *reinterpret_cast<c2f4*>(p.y + o) = c2f4{r4[0], r4[1], r4[2], r4[3]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (cb + r < p.Cout) p.y[o + r * p.ycs] = r4[r];
+    }
+}
+
 template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
 __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
     using G = C2Geom<KH, KW, S, U8, NCHW3>;
     constexpr int WN = 4 / WM, MTW = 16 / WM, STEPS = G::STEPS, PB = G::PB, PLANE = G::PLANE;
-    // 8-channel chunks are short (3 .. 7 K steps): the next chunk's global reads go straight into a per-thread LDS scratch by
-    // LDS-DMA while this chunk's MFMAs run, so that only their conversion, not their latency, sits between two chunks
-    constexpr bool PF = U8 == 1 && !NCHW3;
-    constexpr int RAW0 = 2 * PLANE, RAWB = G::NIT * 4096, WMAX0 = RAW0 + (PF ? 2 * RAWB : 0);
-    extern __shared__ __attribute__((aligned(16))) char patch[];  // [term][row][column parity][column / S][PB] | scratch | 4 floats
-    float* const wmax = reinterpret_cast<float*>(patch + WMAX0);
+    // (Measured and dropped: the next chunk's global reads sent to a per-thread LDS scratch by LDS-DMA under this chunk's MFMAs.
+    // vmcnt retires in order, so the weight fragments of the next K step then wait for those slow reads: 5-10 % slower.)
+    extern __shared__ __attribute__((aligned(16))) char patch[];  // [term][row][column parity][column / S][PB] | 4 floats
+    float* const wmax = reinterpret_cast<float*>(patch + 2 * PLANE);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int g = lane >> 4, px16 = lane & 15;
@@ -184,7 +213,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
     const int cls = bx % p.ncls; bx /= p.ncls;
     const int tx = bx % p.tiles_x; bx /= p.tiles_x;
     const int ty = bx % p.tiles_y;
-    const int b = bx / p.tiles_y;
+    const int b = bx / p.tiles_y;               // output image: (batch element, output plane) for a 3-D layer
+    const int od = b % p.Do, bb = b / p.Do;
     const int ca = cls >> 1, cb2 = cls & 1;  // (0, 0) for a plain convolution
     const int oy0 = ty * C2_TH, ox0 = tx * C2_TW;
     const int iy0 = oy0 * S - (p.pad_y - ca), ix0 = ox0 * S - (p.pad_x - cb2);
@@ -214,7 +244,6 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
 
     // staging items of this thread: global offset (floats, without the chunk's channel offset; -1 = outside the image) and LDS byte
     long long goff[G::NIT];
-    unsigned gvo[G::NIT];  // PF: byte offset from p.x (beyond the descriptor's bound = reads zeros)
     int loff[G::NIT];
 #pragma unroll
     for (int k = 0; k < G::NIT; ++k) {
@@ -227,27 +256,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
         if constexpr (NCHW3) {
             goff[k] = inside ? ((long long)b * 3 * p.Hi + iy) * p.Wi + ix : -1;
             loff[k] = live ? pix * PB : -1;
-        } else {
-            goff[k] = inside ? (((long long)b * p.Hi + iy) * p.Wi + ix) * p.xs + c8 * 8 : -1;
+        } else {  // inside its input image; the image (plane) is the chunk's
+            goff[k] = inside ? ((long long)iy * p.Wi + ix) * p.xs + c8 * 8 : -1;
             loff[k] = live ? ((py * S + pxx % S) * G::PWS + pxx / S) * PB + c8 * 16 : -1;
         }
-        gvo[k] = inside ? (unsigned)(goff[k] * 4) : 0xF0000000u;
     }
-    c2u4 rsrc;
-    if constexpr (PF) {
-        const unsigned long long xa = reinterpret_cast<unsigned long long>(p.x);
-        rsrc = c2u4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa),
-                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xa >> 32)) & 0xffffu, p.x_bytes, 0x00020000u};
-    }
-    const unsigned wv_lds = (unsigned)__builtin_amdgcn_readfirstlane(wv) * 1024u;  // the wave's 1 KB of each scratch row (scalar: goes to M0)
-    auto dma_chunk = [&](int chunk) {
-#pragma unroll
-        for (int k = 0; k < G::NIT; ++k) {
-            c2_lds_dma_b128(rsrc, gvo[k] + (unsigned)chunk * 32u, (unsigned)(RAW0 + k * 4096) + wv_lds);
-            c2_lds_dma_b128(rsrc, gvo[k] + (unsigned)chunk * 32u + 16u, (unsigned)(RAW0 + RAWB + k * 4096) + wv_lds);
-        }
-    };
-
     // activation fragment address of this lane per K step (row 0 of the wave's rows)
     int tapoff[STEPS];
 #pragma unroll
@@ -287,45 +300,24 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
         }
     }
 
-    if constexpr (PF)
-        if (c_begin < c_end) dma_chunk(c_begin);
-
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         // ---- stage the chunk's patch: global fp32 -> two fp16 terms -> LDS -------------------------------------------------------
-        if constexpr (PF) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's scratch has landed (and the weight fragments)
-            __syncthreads();                                  // every wave has finished reading the previous chunk's patch
-            if (!(C2_KO & 1) || chunk == c_begin) {
-#pragma unroll
-                for (int k = 0; k < G::NIT; ++k) {
-                    if (loff[k] < 0) continue;
-                    const c2f4 a0 = *reinterpret_cast<const c2f4*>(patch + RAW0 + (k * 256 + tid) * 16);
-                    const c2f4 a1 = *reinterpret_cast<const c2f4*>(patch + RAW0 + RAWB + (k * 256 + tid) * 16);
-                    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-                    split2(a0[0], a0[1], h0, l0);
-                    split2(a0[2], a0[3], h1, l1);
-                    split2(a1[0], a1[1], h2, l2);
-                    split2(a1[2], a1[3], h3, l3);
-                    *reinterpret_cast<c2u4*>(patch + loff[k]) = c2u4{h0, h1, h2, h3};
-                    *reinterpret_cast<c2u4*>(patch + loff[k] + PLANE) = c2u4{l0, l1, l2, l3};
-                }
-            }
-            __syncthreads();
-            if (chunk + 1 < c_end && !(C2_KO & 1)) dma_chunk(chunk + 1);  // the thread has consumed its scratch: refill it under the MFMAs
-        } else if (!(C2_KO & 1) || chunk == c_begin) {
+        if (!(C2_KO & 1) || chunk == c_begin) {
             c2f4 v0[G::NIT], v1[G::NIT];
+            const int kd = chunk / p.nchunks_c, zi = od * p.SD - p.pad_d + kd;  // the input plane of this chunk (0 for a 2-D layer)
+            const bool zlive = zi >= 0 && zi < p.Di;
+            const float* xim = p.x + ((size_t)bb * p.Di + (zlive ? zi : 0)) * p.Hi * p.Wi * p.xs + (size_t)(chunk - kd * p.nchunks_c) * G::CC;
 #pragma unroll
             for (int k = 0; k < G::NIT; ++k) {
                 v0[k] = c2f4{0, 0, 0, 0};
                 v1[k] = c2f4{0, 0, 0, 0};
-                if (goff[k] >= 0) {
+                if (goff[k] >= 0 && zlive) {
                     if constexpr (NCHW3) {
                         const size_t pl = (size_t)p.Hi * p.Wi;
                         v0[k][0] = p.x[goff[k]]; v0[k][1] = p.x[goff[k] + pl]; v0[k][2] = p.x[goff[k] + 2 * pl];
                     } else {
-                        const float* src = p.x + goff[k] + (size_t)chunk * G::CC;
-                        v0[k] = *reinterpret_cast<const c2f4*>(src);
-                        v1[k] = *reinterpret_cast<const c2f4*>(src + 4);
+                        v0[k] = *reinterpret_cast<const c2f4*>(xim + goff[k]);
+                        v1[k] = *reinterpret_cast<const c2f4*>(xim + goff[k] + 4);
                     }
                 }
             }
@@ -410,32 +402,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
             continue;
         }
         if (cb >= p.Cout || ((C2_KO & 16) && p.B > 1000)) continue;
-        const c2f4 eu = *reinterpret_cast<const c2f4*>(p.eun + cb);
-        float bs[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bs[r] = (p.bias && cb + r < p.Cout) ? p.bias[cb + r] : 0.f;
         if (ox < p.Wo)
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const int oy = oy0 + wm * MTW + m;
-                if (oy >= p.Ho) continue;
-                float* dst = p.y + (size_t)b * p.ys_img + ((size_t)oy * p.oy_mul + ca) * p.ys_row + ((size_t)ox * p.ox_mul + cb2) * p.ys + cb * p.ycs;
-                float r4[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = fmaf(acc[m][t][r], eu[r] * xsc_inv, bs[r]);
-                    if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-                    else if (p.act == 2) v = fmaxf(v, 0.f);
-                    r4[r] = v;
-                    if (cb + r < p.Cout) amax = fmaxf(amax, finite_abs_or_zero(v));
-                }
-                if (cb + 3 < p.Cout && p.ycs == 1) {
-                    *reinterpret_cast<c2f4*>(dst) = c2f4{r4[0], r4[1], r4[2], r4[3]};
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (cb + r < p.Cout) dst[r * p.ycs] = r4[r];
-                }
+                if (oy < p.Ho) c2_finish(p, b, oy, ox, cls, cb, acc[m][t], xsc_inv, amax);
             }
     }
     if (p.yamax && !p.part) {
@@ -444,7 +415,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
         __syncthreads();
         if (tid == 0) {
             amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.yamax), __float_as_uint(amax));
+            raise_absmax(p.yamax, amax);
         }
     }
 }
@@ -485,26 +456,7 @@ __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
             s += v1;
         }
         const int ox = (int)(pl % p.Wo), oy = (int)((pl / p.Wo) % p.Ho), b = (int)(pl / ((long long)p.Wo * p.Ho));
-        float* dst = p.y + (size_t)b * p.ys_img + ((size_t)oy * p.oy_mul + (cls >> 1)) * p.ys_row + ((size_t)ox * p.ox_mul + (cls & 1)) * p.ys + cb * p.ycs;
-        float r4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = 0.f;
-            if (cb + r < p.Cout) {
-                v = fmaf(s[r], p.eun[cb + r] * xsc_inv, p.bias ? p.bias[cb + r] : 0.f);
-                if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-                else if (p.act == 2) v = fmaxf(v, 0.f);
-                amax = fmaxf(amax, finite_abs_or_zero(v));
-            }
-            r4[r] = v;
-        }
-        if (cb + 3 < p.Cout && p.ycs == 1) {
-            *reinterpret_cast<c2f4*>(dst) = c2f4{r4[0], r4[1], r4[2], r4[3]};
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (cb + r < p.Cout) dst[r * p.ycs] = r4[r];
-        }
+        c2_finish(p, b, oy, ox, cls, cb, s, xsc_inv, amax);
     }
     if (p.yamax) {
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
@@ -512,7 +464,7 @@ __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
         __syncthreads();
         if (threadIdx.x == 0) {
             amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.yamax), __float_as_uint(amax));
+            raise_absmax(p.yamax, amax);
         }
     }
 }
@@ -545,8 +497,70 @@ __global__ void __launch_bounds__(256) upsample2x_nhwc_kernel(const float* __res
         __syncthreads();
         if (threadIdx.x == 0) {
             amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(yamax), __float_as_uint(amax));
+            raise_absmax(yamax, amax);
         }
+    }
+}
+
+// ---- 3-D layers of the regulariser (K4) on the same kernel ------------------------------------------------------------------------
+// Conv3d (Cout, Cin, 3, 3, 3), padding 1, stride 1 or 2: the depth taps are chunks (chunk = kd * nchunks_c + c), the in-plane taps the
+// 3 x 3 of the 2-D kernel.  ConvTranspose3d (Cin, Cout, 3, 3, 3), stride 2, padding 1, output_padding 1: output voxel 2 i + a takes,
+// per dimension, kernel element 1 from input i (a = 0), or elements 2 and 0 from inputs i and i + 1 (a = 1): a 2 x 2 x 2 convolution
+// over the input grid (tap t reads input i + t) with 8 Cout output channels (parity class k3 = 4 ad + 2 ay + ax, channel c) at
+// k3 * Cout + c, zero weights where a class has no such tap.
+__device__ __forceinline__ int c3_deconv_kidx(int a, int t) { return a == 0 ? (t == 0 ? 1 : -1) : (t == 0 ? 2 : 0); }
+
+__global__ void c3_pack_kernel(const float* __restrict__ w, const float* __restrict__ eun, _Float16* __restrict__ packed, int Cin, int Cout,
+                               int U8, int nchunks_c, int ntiles, int steps, int transposed, long long total) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int KD = transposed ? 2 : 3, KP = transposed ? 2 : 3;  // depth taps, in-plane taps per dimension
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), term = (int)((e >> 9) & 1);
+    long long r = e >> 10;
+    const int step = (int)(r % steps); r /= steps;
+    const int chunk = (int)(r % (KD * nchunks_c)); r /= KD * nchunks_c;
+    const int nt = (int)r;
+    const int kd = chunk / nchunks_c, cc = chunk % nchunks_c;
+    const int ce = nt * 16 + (lane & 15), unit = 4 * step + (lane >> 4);
+    const int tap = unit / U8, cin = cc * 8 * U8 + 8 * (unit % U8) + j;
+    const int ncout = transposed ? 8 * Cout : Cout;
+    float v = 0.f;
+    if (tap < KP * KP && cin < Cin && ce < ncout) {
+        const int ty = tap / KP, tx = tap % KP;
+        if (transposed) {
+            const int k3 = ce / Cout, c = ce % Cout;
+            const int kz = c3_deconv_kidx(k3 >> 2, kd), ky = c3_deconv_kidx((k3 >> 1) & 1, ty), kx = c3_deconv_kidx(k3 & 1, tx);
+            if (kz >= 0 && ky >= 0 && kx >= 0) v = w[((((size_t)cin * Cout + c) * 3 + kz) * 3 + ky) * 3 + kx];
+        } else {
+            v = w[((((size_t)ce * Cin + cin) * 3 + kd) * 3 + ty) * 3 + tx];
+        }
+        v = v / eun[ce];
+    }
+    const _Float16 hi = (_Float16)v;
+    packed[e] = term == 0 ? hi : (_Float16)(v - (float)hi);
+}
+
+// 2^k_c per (class,) channel: max |w| over all of the channel's weights (for the transposed form shared by its 8 classes)
+__global__ void c3_wscale_kernel(const float* __restrict__ w, float* __restrict__ eun, int Cin, int Cout, int transposed, int ncout, int cpad) {
+    __shared__ float red[256];
+    const int ce = blockIdx.x, c = ce % Cout;
+    float m = 0.f;
+    if (ce < ncout)
+        for (int e = threadIdx.x; e < Cin * 27; e += 256) {
+            const int ci = e / 27, t = e % 27;
+            const float v = fabsf(transposed ? w[((size_t)ci * Cout + c) * 27 + t] : w[((size_t)c * Cin + ci) * 27 + t]);
+            m = (v <= 3.4e38f && v > m) ? v : m;
+        }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && ce < cpad) {
+        const int ex = (int)((__float_as_uint(red[0]) >> 23) & 0xffu) - 127;
+        const int k = red[0] > 0.f ? max(-100, min(100, ex - 10)) : 0;
+        eun[ce] = ldexpf(1.0f, k);
     }
 }
 
@@ -622,8 +636,7 @@ template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
 static int c2_launch(const C2Params& p, long long nblk, hipStream_t st) {
     using G = C2Geom<KH, KW, S, U8, NCHW3>;
     auto kern = conv2d_split_kernel<KH, KW, S, U8, WM, NTW, NCHW3>;
-    constexpr bool PF = U8 == 1 && !NCHW3;
-    constexpr int lds = 2 * G::PLANE + (PF ? 2 * G::NIT * 4096 : 0) + 16;
+    constexpr int lds = 2 * G::PLANE + 16;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return launch_status("conv2d_split: LDS attribute");
@@ -646,7 +659,7 @@ static int c2_launch_bn(const C2Params& p, int bn, long long nblk, hipStream_t s
 static int c2_dispatch(const C2Shape& s, const C2Params& p, int bn, long long nblk, hipStream_t st) {
     if (s.nchw3) return c2_launch_bn<7, 7, 2, 1, true>(p, bn, nblk, st);
     if (s.KH == 1) return c2_launch_bn<1, 1, 1, 4, false>(p, bn, nblk, st);
-    if (s.KH == 2) return c2_launch_bn<2, 2, 1, 4, false>(p, bn, nblk, st);
+    if (s.KH == 2) return s.U8 == 4 ? c2_launch_bn<2, 2, 1, 4, false>(p, bn, nblk, st) : c2_launch_bn<2, 2, 1, 2, false>(p, bn, nblk, st);
     if (s.KH == 5) return c2_launch_bn<5, 5, 2, 1, false>(p, bn, nblk, st);
     if (s.S == 2) return c2_launch_bn<3, 3, 2, 1, false>(p, bn, nblk, st);
     if (s.U8 == 4) return c2_launch_bn<3, 3, 1, 4, false>(p, bn, nblk, st);
@@ -707,12 +720,8 @@ int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* pack
     mvd::C2Params p{};
     p.x = x; p.xamax = x_absmax; p.bias = bias; p.y = y; p.yamax = y_absmax;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.xs = x_pixel_stride; p.nchunks = Cin_pad / (8 * s.U8);
+    p.Di = p.Do = p.Dy = p.KD = p.SD = 1; p.pad_d = 0; p.nchunks_c = p.nchunks; p.sub3d = 0; p.Cr = Cout;
     p.Cout = Cout; p.ys = y_pixel_stride; p.act = act; p.slope = slope;
-    if (mode != 2) {
-        const long long xb = ((long long)B * Hi * Wi - 1) * x_pixel_stride * 4 + (long long)Cin_pad * 4;
-        MVD_REQUIRE(xb < 0x70000000LL, "conv2d_split: input of %lld bytes exceeds the 31-bit offset range", xb);
-        p.x_bytes = (unsigned)xb;
-    }
     const size_t fb = mvd::c2_frag_bytes(s, Cin_pad, Cout);
     p.eun = reinterpret_cast<const float*>(static_cast<const char*>(packed_w) + fb);
     const mvd::C2Plan q = mvd::c2_plan(s, B, Hi, Wi, Cin_pad, Cout, KH, KW, stride);
@@ -755,5 +764,123 @@ int mvd_upsample2x_nhwc_f32(const float* x, float* y, float* y_absmax, int B, in
     hipLaunchKernelGGL(mvd::upsample2x_nhwc_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, y,
                        y_absmax, B, C, h, w, y_pixel_stride);
     return mvd::launch_status("upsample2x_nhwc");
+}
+
+/* ---- 3-D layers ---- */
+}  // extern "C"
+
+namespace mvd {
+// mode: MVD_CONV3D_STRIDE1 / MVD_CONV3D_STRIDE2 / MVD_DECONV3D_STRIDE2 (mvd.h)
+static bool c3_shape(int Cin, int Cout, int mode, C2Shape* s, int* ncout) {
+    if (Cin <= 0 || Cin % 8 || Cout <= 0 || Cout % 4 || mode < 0 || mode > 2) return false;
+    s->transposed = false; s->nchw3 = false;
+    if (mode == MVD_DECONV3D_STRIDE2) {
+        if (Cin % 16) return false;
+        s->KH = s->KW = 2; s->S = 1; s->U8 = Cin % 32 == 0 ? 4 : 2;
+        *ncout = 8 * Cout;
+    } else {
+        s->KH = s->KW = 3; s->S = mode == MVD_CONV3D_STRIDE2 ? 2 : 1;
+        s->U8 = (s->S == 1 && Cin % 32 == 0) ? 4 : 1;
+        *ncout = Cout;
+    }
+    s->steps = (s->KH * s->KW * s->U8 + 3) / 4;
+    return true;
+}
+static size_t c3_frag_bytes(const C2Shape& s, int Cin, int ncout, int mode) {
+    const size_t KD = mode == MVD_DECONV3D_STRIDE2 ? 2 : 3;
+    return (size_t)c2_ntiles(ncout) * KD * (Cin / (8 * s.U8)) * s.steps * 2048;
+}
+}  // namespace mvd
+
+extern "C" {
+
+size_t mvd_conv3d_igemm_packed_weight_bytes(int Cin, int Cout, int mode) {
+    mvd::C2Shape s;
+    int ncout;
+    if (!mvd::c3_shape(Cin, Cout, mode, &s, &ncout)) return 0;
+    return mvd::c3_frag_bytes(s, Cin, ncout, mode) + (size_t)mvd::c2_cpad(ncout) * sizeof(float);
+}
+
+int mvd_pack_conv3d_weights_igemm(const float* w, int Cin, int Cout, int mode, void* packed, mvd_stream_t stream) {
+    MVD_REQUIRE(w && packed, "pack_conv3d_weights_igemm: NULL argument");
+    mvd::C2Shape s;
+    int ncout;
+    MVD_REQUIRE(mvd::c3_shape(Cin, Cout, mode, &s, &ncout), "pack_conv3d_weights_igemm: %d -> %d channels, mode %d is not built", Cin, Cout, mode);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t fb = mvd::c3_frag_bytes(s, Cin, ncout, mode);
+    float* eun = reinterpret_cast<float*>(static_cast<char*>(packed) + fb);
+    const int cpad = mvd::c2_cpad(ncout), tr = mode == MVD_DECONV3D_STRIDE2 ? 1 : 0;
+    hipLaunchKernelGGL(mvd::c3_wscale_kernel, dim3(cpad), dim3(256), 0, st, w, eun, Cin, Cout, tr, ncout, cpad);
+    const long long total = (long long)(fb / 2);
+    hipLaunchKernelGGL(mvd::c3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, eun, (_Float16*)packed, Cin, Cout, s.U8,
+                       Cin / (8 * s.U8), mvd::c2_ntiles(ncout), s.steps, tr, total);
+    return mvd::launch_status("pack_conv3d_weights_igemm");
+}
+
+static mvd::C2Plan c3_plan(const mvd::C2Shape& s, int B, int Di, int Hi, int Wi, int Cin, int ncout, int mode, int* Do) {
+    mvd::C2Plan q{};
+    const int sd = mode == MVD_CONV3D_STRIDE2 ? 2 : 1;
+    *Do = Di / sd; q.Ho = Hi / sd; q.Wo = Wi / sd; q.ncls = 1;
+    q.tiles_y = (q.Ho + mvd::C2_TH - 1) / mvd::C2_TH;
+    q.tiles_x = (q.Wo + mvd::C2_TW - 1) / mvd::C2_TW;
+    q.bn = mvd::c2_bn(ncout);
+    q.nblocks = (ncout + q.bn - 1) / q.bn;
+    q.ncp = q.nblocks * q.bn;
+    q.nchunks = (mode == MVD_DECONV3D_STRIDE2 ? 2 : 3) * (Cin / (8 * s.U8));
+    q.tiles = (long long)q.tiles_x * q.tiles_y * B * *Do * q.nblocks;
+    q.ksplit = 1;
+    if (q.tiles < 128)
+        while (q.tiles * q.ksplit < 320 && q.ksplit < 32 && q.nchunks / (q.ksplit * 2) >= 2) q.ksplit *= 2;
+    q.part_bytes = q.ksplit > 1 ? (size_t)q.ksplit * B * *Do * q.Ho * q.Wo * q.ncp * sizeof(float) : 0;
+    return q;
+}
+
+size_t mvd_conv3d_igemm_workspace_bytes(int B, int Di, int Hi, int Wi, int Cin, int Cout, int mode) {
+    mvd::C2Shape s;
+    int ncout, Do;
+    if (B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || !mvd::c3_shape(Cin, Cout, mode, &s, &ncout)) return 0;
+    return c3_plan(s, B, Di, Hi, Wi, Cin, ncout, mode, &Do).part_bytes;
+}
+
+int mvd_conv3d_bn_relu_igemm_f32(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
+                                 const float* skip, float* y, float* y_absmax, int B, int Di, int Hi, int Wi, int Cin, int Cout, int mode,
+                                 int relu, void* workspace, size_t workspace_bytes, mvd_stream_t stream) {
+    MVD_REQUIRE(x && x_absmax && packed_w && scale && shift && y, "conv3d_igemm: NULL argument");
+    MVD_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv3d_igemm: non-positive dimension");
+    mvd::C2Shape s;
+    int ncout;
+    MVD_REQUIRE(mvd::c3_shape(Cin, Cout, mode, &s, &ncout), "conv3d_igemm: %d -> %d channels, mode %d is not built", Cin, Cout, mode);
+    MVD_REQUIRE(mode != MVD_CONV3D_STRIDE2 || (Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0), "conv3d_igemm stride 2: odd input dims %dx%dx%d", Di, Hi, Wi);
+    MVD_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)skip) & 15) == 0, "conv3d_igemm: x, y and skip must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int Do;
+    const mvd::C2Plan q = c3_plan(s, B, Di, Hi, Wi, Cin, ncout, mode, &Do);
+    const bool tr = mode == MVD_DECONV3D_STRIDE2;
+    mvd::C2Params p{};
+    p.x = x; p.xamax = x_absmax; p.bias = shift; p.scale = scale; p.skip = skip; p.y = y; p.yamax = y_absmax;
+    p.wpk = static_cast<const char*>(packed_w);
+    p.eun = reinterpret_cast<const float*>(p.wpk + mvd::c3_frag_bytes(s, Cin, ncout, mode));
+    p.B = B * Do; p.Hi = Hi; p.Wi = Wi; p.xs = Cin; p.nchunks = q.nchunks;
+    p.Di = Di; p.Do = Do; p.KD = tr ? 2 : 3; p.SD = mode == MVD_CONV3D_STRIDE2 ? 2 : 1; p.pad_d = tr ? 0 : 1; p.nchunks_c = Cin / (8 * s.U8);
+    p.sub3d = tr ? 1 : 0; p.Cr = Cout; p.Dy = tr ? 2 * Di : Do;
+    p.Ho = q.Ho; p.Wo = q.Wo; p.Hy = tr ? 2 * Hi : q.Ho; p.Wy = tr ? 2 * Wi : q.Wo;
+    p.oy_mul = p.ox_mul = 1; p.pad_y = p.pad_x = tr ? 0 : 1;
+    p.Cout = ncout; p.ncp = q.ncp; p.ys = Cout; p.ycs = 1;
+    p.ys_row = (long long)p.Wy * Cout; p.ys_img = (long long)p.Hy * p.ys_row;
+    p.tiles_x = q.tiles_x; p.tiles_y = q.tiles_y; p.nblocks = q.nblocks; p.ncls = 1; p.cls_bytes = 0;
+    p.act = relu ? 2 : 0; p.slope = 0.f;
+    int ksplit = q.ksplit;
+    if (ksplit > 1 && (!workspace || workspace_bytes < q.part_bytes)) ksplit = 1;
+    p.ksplit = ksplit;
+    p.chunks_per_split = (p.nchunks + ksplit - 1) / ksplit;
+    p.part = ksplit > 1 ? static_cast<float*>(workspace) : nullptr;
+    const long long nblk = q.tiles * ksplit;
+    MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv3d_igemm: %lld workgroups exceed the grid limit", nblk);
+    if (y_absmax && hipMemsetAsync(y_absmax, 0, sizeof(float), st) != hipSuccess) return mvd::launch_status("conv3d_igemm: memset");
+    int rc = mvd::c2_dispatch(s, p, q.bn, nblk, st);
+    if (rc != MVD_OK || ksplit == 1) return rc;
+    const long long n = (long long)p.B * p.Ho * p.Wo * ((p.Cout + 3) / 4);
+    hipLaunchKernelGGL(mvd::c2_reduce_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 512)), dim3(256), 0, st, p);
+    return mvd::launch_status("conv3d_igemm: reduce");
 }
 }

@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
         __syncthreads();
         if (tid == 0) {
             amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.absmax), __float_as_uint(amax));
+            raise_absmax(p.absmax, amax);
         }
     }
 }

@@ -111,6 +111,7 @@ struct SplitParams {
     const float* shift;
     const float* absmax;  // max |x| (device, one float): sets the activations' power-of-two scale
     float* y;             // (B, D, h, w, Cout) fp32
+    float* yamax;         // optional (device, one float, zeroed by the launcher): max |y| over the finite outputs
     int B, D, h, w, relu;
     int cout, ncb;        // output channels (a multiple of 8) and Cout / 8: one workgroup computes 8 of them
     int tiles_x, tiles_y, dgroups, td, tiles_per_xcd;
@@ -128,7 +129,7 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 // clocks of MFMA and the kernel sat on the LDS port at 35 % matrix utilisation.  Three output planes of accumulators are in
 // flight per wave (48 VGPRs); the LDS holds two plane slots (the one being read, the one being written).
 // wave wv: columns 16 (wv & 1) .. +15, output rows 2 (wv >> 1), +1 of the 4 x 32 tile.
-template <int CIN>
+template <int CIN, bool YAMAX = false>  // YAMAX: also max |y| (a variant of its own: the extra epilogue work costs the plain one 7 %)
 __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     using G = SplitGeom<CIN>;
     constexpr int S_COLS = G::COLS, S_HALF_BYTES = G::HALF_BYTES, S_PLANE_BYTES = G::PLANE_BYTES, S_ITEMS = G::ITEMS, S_NLOAD = G::NLOAD;
@@ -285,6 +286,7 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
     // every staging phase (50 % busy).
     // With loads AND stores outstanding the compiler has to treat vmcnt as unordered: the first use of a prefetched register
     // (pass B, group 8) becomes a full flush.  By then the youngest load is two thirds of a step old and the stores a full one.
+    [[maybe_unused]] float amax_ = 0.f;  // max |y| of this lane's stored values (YAMAX)
     for (int z = dz0 - 1; z <= dz1; ++z) {
         if (!(SPLIT_KO & 8)) __syncthreads();  // plane z is staged; the other slot (plane z-1) has been read by every wave
         const char* slot = ring + (z & 1) * S_PLANE_BYTES;
@@ -348,6 +350,8 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
                 if (g + 1 < 8) hl = __shfl_down(acc[0][(g + 1) >> 2][0][(g + 1) & 3], 8, 16);
                 float r = __builtin_fmaf(cur + acc[0][row][1][i], 1.0f / 2048.0f, acc[0][row][0][i]);
                 r = fmaxf(__builtin_fmaf(r * eun_, esc_, esh_), floor_);
+                if constexpr (YAMAX)
+                    if (out_ok && yoff[row] != OOB && ox + i < w) amax_ = fmaxf(amax_, finite_abs_or_zero(r));
                 if (!(SPLIT_KO & 2) || r == 12345.678f)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs_out, ox + i < w ? yoff[row] + vox_b * i : OOB, 0, 0);
             } else if (!(SPLIT_KO & 4)) {  // staging of plane z+1 / reload with plane z+2: item k, float pair q of its 4
@@ -378,6 +382,17 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
                 acc[2][r][t] = sf32x4{0, 0, 0, 0};
             }
     }
+    if constexpr (YAMAX) {  // what a following split-operand layer scales its activations by: ONE atomic per workgroup
+        for (int o = 32; o > 0; o >>= 1) amax_ = fmaxf(amax_, __shfl_xor(amax_, o));
+        __syncthreads();  // the ring is free
+        float* wm = reinterpret_cast<float*>(ring);
+        if (lane == 0) wm[wv] = amax_;
+        __syncthreads();
+        if (tid == 0) {
+            amax_ = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+            raise_absmax(p.yamax, amax_);
+        }
+    }
 }
 
 }  // namespace mvd
@@ -385,12 +400,16 @@ __global__ void __launch_bounds__(256, 2) conv0_split_kernel(SplitParams p) {
 static bool split_shape_ok(int Cin, int Cout) { return (Cin == 32 || Cin == 16) && Cout >= 8 && Cout <= 64 && Cout % 8 == 0; }
 static size_t split_frag_bytes(int Cin, int Cout) { return (size_t)(Cout / 8) * (Cin == 32 ? 27 : 18) * 64 * 16; }
 
+template <int CIN, bool YAMAX>
+static int launch_split_v(const mvd::SplitParams& p, long long nblk, hipStream_t st) {
+    const size_t lds = 2 * (size_t)mvd::SplitGeom<CIN>::PLANE_BYTES + 256 * 16;  // two slots + the dump row
+    (void)hipFuncSetAttribute((const void*)mvd::conv0_split_kernel<CIN, YAMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mvd::conv0_split_kernel<CIN, YAMAX>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+    return mvd::launch_status("conv3d_split");
+}
 template <int CIN>
 static int launch_split(const mvd::SplitParams& p, long long nblk, hipStream_t st) {
-    const size_t lds = 2 * (size_t)mvd::SplitGeom<CIN>::PLANE_BYTES + 256 * 16;  // two slots + the dump row
-    (void)hipFuncSetAttribute((const void*)mvd::conv0_split_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mvd::conv0_split_kernel<CIN>, dim3((unsigned)nblk), dim3(256), lds, st, p);
-    return mvd::launch_status("conv3d_split");
+    return p.yamax ? launch_split_v<CIN, true>(p, nblk, st) : launch_split_v<CIN, false>(p, nblk, st);
 }
 
 extern "C" {
@@ -411,15 +430,31 @@ int mvd_pack_conv3d_weights_split(const float* w, int Cin, int Cout, void* packe
     return mvd::launch_status("pack_conv3d_weights_split");
 }
 
+static int conv3d_split_entry(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift, float* y,
+                              float* y_absmax, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream);
+
 int mvd_conv3d_bn_relu_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
                                  float* y, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream) {
+    return conv3d_split_entry(x, x_absmax, packed_w, scale, shift, y, nullptr, B, D, h, w, Cin, Cout, relu, stream);
+}
+
+int mvd_conv3d_bn_relu_absmax_f32_split(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift,
+                                        float* y, float* y_absmax, int B, int D, int h, int w, int Cin, int Cout, int relu,
+                                        mvd_stream_t stream) {
+    MVD_REQUIRE(y_absmax, "conv3d_split_absmax: NULL argument");
+    return conv3d_split_entry(x, x_absmax, packed_w, scale, shift, y, y_absmax, B, D, h, w, Cin, Cout, relu, stream);
+}
+
+static int conv3d_split_entry(const float* x, const float* x_absmax, const void* packed_w, const float* scale, const float* shift, float* y,
+                              float* y_absmax, int B, int D, int h, int w, int Cin, int Cout, int relu, mvd_stream_t stream) {
     MVD_REQUIRE(x && x_absmax && packed_w && scale && shift && y, "conv3d_split: NULL argument");
     MVD_REQUIRE(split_shape_ok(Cin, Cout), "conv3d_split: 16 or 32 input channels and 8, 16, ... 64 output channels are built (got %d -> %d)", Cin, Cout);
     MVD_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "conv3d_split: non-positive dimension");
     MVD_REQUIRE((long long)h * w * Cin * 4 < 0x7fffffffLL && (long long)h * w * Cout * 4 < 0x7fffffffLL,
                 "conv3d_split: one plane exceeds the 31-bit byte-offset range");
     mvd::SplitParams p{};
-    p.x = x; p.absmax = x_absmax; p.wpk = (const char*)packed_w; p.scale = scale; p.shift = shift; p.y = y;
+    p.x = x; p.absmax = x_absmax; p.wpk = (const char*)packed_w; p.scale = scale; p.shift = shift; p.y = y; p.yamax = y_absmax;
+    if (y_absmax && hipMemsetAsync(y_absmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return mvd::launch_status("conv3d_split: memset");
     p.B = B; p.D = D; p.h = h; p.w = w; p.relu = relu;
     p.cout = Cout; p.ncb = Cout / 8;
     p.tiles_x = (w + mvd::S_TW - 1) / mvd::S_TW;

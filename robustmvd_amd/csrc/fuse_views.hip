@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) fuse_views_nhwc_kernel(FuseNhwcParams p) 
         __syncthreads();
         if (threadIdx.x == 0) {
             am = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (am > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.amax), __float_as_uint(am));
+            raise_absmax(p.amax, am);
         }
     }
 }

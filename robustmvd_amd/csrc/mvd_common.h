@@ -14,6 +14,11 @@ void timing_begin(hipStream_t st);
 void timing_end(hipStream_t st);
 // max |x| over the finite values of n floats into *absmax (device, one float; zeroed first): warp_variance.hip
 int absmax_launch(const float* x, long long n, float* absmax, hipStream_t st);
+// Raise *slot (a non-negative float kept as its bit pattern) to m.  Atomics on one address serialise (~10 ns each), and after the
+// first few workgroups of a launch most arrive with a smaller value: those find that out with a plain load and leave.
+__device__ __forceinline__ void raise_absmax(float* slot, float m) {
+    if (m > 0.f && m > __builtin_nontemporal_load(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+}
 __device__ __forceinline__ float finite_abs_or_zero(float v) {
     const float a = fabsf(v);
     return a <= 3.402823466e38f ? a : 0.f;  // false for inf and NaN

@@ -1260,15 +1260,16 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
     // ONE atomic per workgroup: atomics on a single address serialise at ~10 ns each
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+        raise_absmax(reinterpret_cast<float*>(out), m);
     }
 }
 
 int absmax_launch(const float* x, long long n, float* absmax, hipStream_t st) {
     if (hipMemsetAsync(absmax, 0, sizeof(float), st) != hipSuccess) return launch_status("absmax: memset");
     if (n <= 0) return MVD_OK;
-    const long long want = (n / 4 + 255) / 256;
-    const unsigned nblk = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));  // 8 workgroups per CU, grid-stride
+    // grid-stride, 4 loads of 16 bytes in flight per thread, up to 16 workgroups per CU; a workgroup ends with at most one atomic
+    const long long want = (n / 4 + 1023) / 1024;
+    const unsigned nblk = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
     hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(absmax));
     return launch_status("absmax");
 }

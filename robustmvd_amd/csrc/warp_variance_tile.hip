@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256, MINW) warp_variance_tile_kernel(WarpParam
         __syncthreads();  // every wave is past its last use of the probe words
         if ((tid & 63) == 63) wm[wv] = m;
         __syncthreads();
-        if (tid == 0) atomicMax(reinterpret_cast<unsigned*>(p.absmax), max(max(wm[0], wm[1]), max(wm[2], wm[3])));
+        if (tid == 0) raise_absmax(p.absmax, __uint_as_float(max(max(wm[0], wm[1]), max(wm[2], wm[3]))));
     }
 }
 

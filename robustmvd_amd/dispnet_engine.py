@@ -109,9 +109,9 @@ class DispnetEngine:
         c3k, a_c3k = e(n, h8, w8, 256), slot()
         # (conv2 reads before the decoder adds to the slots: every later writer only raises them, which stays a valid bound)
         ops.conv2d_split(cat4[..., :128], a_cat4, w["conv3"], out=c3k, out_absmax=a_c3k)
-        s1, a1 = e(V * n, H // 2, W // 2, 64), slot()
-        for v, im in enumerate(images_source):  # one launch per view (a launch fills the chip; no concatenated copy of the images)
-            ops.conv2d_split(im, ops.absmax(im), w["conv1"], out=s1[v * n:(v + 1) * n], out_absmax=a1)
+        # (one launch over the concatenated source images: per-view launches of this layer measured 2.2x slower, tail effects)
+        src = torch.cat(list(images_source), 0) if V > 1 else images_source[0]
+        s1, a1 = layer("conv1", src, ops.absmax(src))
         s2, a2 = layer("conv2", s1, a1)
         del s1
         c3s = bufs["c3s"]

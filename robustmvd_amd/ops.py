@@ -406,12 +406,13 @@ def pack_conv3d_weights_split(weight):
 
 
 @inference_only
-def conv3d_bn_relu_split(x, packed, scale, shift, relu=True, x_absmax=None):
+def conv3d_bn_relu_split(x, packed, scale, shift, relu=True, x_absmax=None, return_absmax=False):
     """K4's stride-1 layers with 16 or 32 input channels (conv0: 32 -> 8, conv2: 16 -> 16, conv4: 32 -> 32), split-operand
     form: x (B,D,h,w,Cin) fp32 -> (B,D,h,w,Cout) fp32 (Cout = len(scale)) on fp16 MFMA with two-term operand
     splitting and power-of-two range scaling (mvd_conv3d_bn_relu_f32_split; fp32-grade results for inputs of any
     magnitude).  x_absmax: one-element device tensor with max |x| (warp_variance(..., return_absmax=True)); computed here
-    with a streaming pass over x when omitted."""
+    with a streaming pass over x when omitted.  return_absmax: also max |y| (one-element device tensor), a by-product of the
+    store epilogue."""
     lib = L.load()
     x = L.as_f32(x, "x")
     if x.dim() != 5 or x.shape[-1] not in (16, 32):
@@ -427,11 +428,76 @@ def conv3d_bn_relu_split(x, packed, scale, shift, relu=True, x_absmax=None):
     if x_absmax is None:
         x_absmax = absmax(x)
     x_absmax = L.as_f32(x_absmax, "x_absmax", (1,), dev)
+    if return_absmax:
+        yam = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.mvd_conv3d_bn_relu_absmax_f32_split(L.ptr(x), L.ptr(x_absmax), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y),
+                                                         L.ptr(yam), B, D, h, w, cin, cout, int(bool(relu)), L.stream_of(x))
+        L.check(rc, "mvd_conv3d_bn_relu_absmax_f32_split")
+        return y, yam
     with torch.cuda.device(dev):
         rc = lib.mvd_conv3d_bn_relu_f32_split(L.ptr(x), L.ptr(x_absmax), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), B, D, h, w,
                                               cin, cout, int(bool(relu)), L.stream_of(x))
     L.check(rc, "mvd_conv3d_bn_relu_f32_split")
     return y
+
+
+@inference_only
+def pack_conv3d_weights_igemm(weight, mode):
+    """weight: Conv3d (Cout,Cin,3,3,3), or ConvTranspose3d (Cin,Cout,3,3,3) for mode DECONV3D_STRIDE2 -> packed split-operand
+    fragments for conv3d_bn_relu_igemm (mvd_pack_conv3d_weights_igemm)."""
+    lib = L.load()
+    wt = L.as_f32(weight, "weight")
+    if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"weight must be (*,*,3,3,3), got {tuple(wt.shape)}")
+    cin, cout = (wt.shape[0], wt.shape[1]) if mode == L.DECONV3D_STRIDE2 else (wt.shape[1], wt.shape[0])
+    n = lib.mvd_conv3d_igemm_packed_weight_bytes(cin, cout, mode)
+    if n == 0:
+        raise ValueError(f"conv3d igemm: {cin} -> {cout} channels, mode {mode} is not built (Cin a multiple of 8 (16 transposed), Cout of 4)")
+    packed = torch.empty(n, dtype=torch.uint8, device=wt.device)
+    with torch.cuda.device(wt.device):
+        rc = lib.mvd_pack_conv3d_weights_igemm(L.ptr(wt), cin, cout, mode, L.ptr(packed), L.stream_of(wt))
+    L.check(rc, "mvd_pack_conv3d_weights_igemm")
+    return packed
+
+
+@inference_only
+def conv3d_bn_relu_igemm(x, x_absmax, packed, Cin, Cout, scale, shift, mode, relu=True, skip=None, return_absmax=False):
+    """K4's stride-2 / transposed / wide stride-1 layers on the split-operand implicit-GEMM kernel (mvd_conv3d_bn_relu_igemm_f32).
+    x (B,D,h,w,Cin) channel-last fp32, x_absmax one-element device tensor with max |x| -> (B,Do,ho,wo,Cout); skip (like the output)
+    is added after the activation.  return_absmax: also max |y|."""
+    lib = L.load()
+    x = L.as_f32(x, "x")
+    if x.dim() != 5 or x.shape[-1] != Cin:
+        raise ValueError(f"x must be (B,D,h,w,{Cin}) channel-last, got {tuple(x.shape)}")
+    B, Di, hi, wi, _ = x.shape
+    dev = x.device
+    if mode == L.CONV3D_STRIDE1:
+        oshape = (B, Di, hi, wi, Cout)
+    elif mode == L.CONV3D_STRIDE2:
+        if Di % 2 or hi % 2 or wi % 2:
+            raise ValueError(f"stride-2 conv needs even D,h,w, got {Di},{hi},{wi}")
+        oshape = (B, Di // 2, hi // 2, wi // 2, Cout)
+    elif mode == L.DECONV3D_STRIDE2:
+        oshape = (B, Di * 2, hi * 2, wi * 2, Cout)
+    else:
+        raise ValueError(f"mode {mode}")
+    if packed.numel() != lib.mvd_conv3d_igemm_packed_weight_bytes(Cin, Cout, mode):
+        raise ValueError(f"packed weights of {packed.numel()} bytes do not belong to a {Cin} -> {Cout} layer of mode {mode}")
+    scale = L.as_f32(scale, "scale", (Cout,), dev)
+    shift = L.as_f32(shift, "shift", (Cout,), dev)
+    if skip is not None:
+        skip = L.as_f32(skip, "skip", oshape, dev)
+    xam = L.as_f32(x_absmax, "x_absmax", (1,), dev)
+    y = torch.empty(oshape, dtype=torch.float32, device=dev)
+    yam = torch.empty(1, dtype=torch.float32, device=dev) if return_absmax else None
+    wsb = lib.mvd_conv3d_igemm_workspace_bytes(B, Di, hi, wi, Cin, Cout, mode)
+    wsp = _workspace(wsb, dev) if wsb else None
+    with torch.cuda.device(dev):
+        rc = lib.mvd_conv3d_bn_relu_igemm_f32(L.ptr(x), L.ptr(xam), L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(skip), L.ptr(y),
+                                              L.ptr(yam), B, Di, hi, wi, Cin, Cout, mode, int(bool(relu)), L.ptr(wsp), wsb, L.stream_of(x))
+    L.check(rc, "mvd_conv3d_bn_relu_igemm_f32")
+    return (y, yam) if return_absmax else y
 
 
 @inference_only

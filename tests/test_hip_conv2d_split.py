@@ -180,3 +180,59 @@ def test_sweep_and_fusion_on_channel_last_layouts_equal_the_planar_entry_points(
     ops.fuse_views_nhwc(c2, m2, scores, out[..., 4:], out_absmax=am)
     assert torch.equal(out[..., 4:].permute(0, 3, 1, 2), fused)
     assert float(am) == float(fused.abs().max()) and float(out[..., :4].min()) == 9.0
+
+
+# ---- K4's 3-D layers on the same kernel -------------------------------------------------------------------------------------
+C3_CASES = [
+    # (mode, cin, cout, B, D, h, w)   mode: 0 stride 1, 1 stride 2, 2 transposed
+    (1, 8, 16, 1, 8, 20, 36), (1, 16, 32, 2, 6, 10, 18), (1, 32, 64, 1, 4, 8, 34),
+    (0, 64, 64, 1, 5, 9, 20), (0, 32, 32, 1, 3, 17, 16), (0, 8, 8, 1, 4, 6, 40),
+    (2, 64, 32, 1, 3, 5, 9), (2, 32, 16, 2, 4, 6, 18), (2, 16, 8, 1, 5, 12, 33),
+]
+
+
+@pytest.mark.parametrize("mode,cin,cout,B,D,h,w", C3_CASES)
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_conv3d_igemm_vs_float64_and_fp32_kernel(mode, cin, cout, B, D, h, w, with_skip, dev):
+    """mvd_conv3d_bn_relu_igemm_f32 (Conv3d 3x3x3 stride 1 / 2, ConvTranspose3d stride 2 with output_padding 1, as in
+    mvsnet_components.py:78-101) against torch's float64 convolution on the CPU and against the fp32-MFMA kernel of the library."""
+    from robustmvd_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(mode * 100 + cin + cout)
+    x = torch.randn(B, cin, D, h, w, generator=g) * torch.rand(1, cin, 1, 1, 1, generator=g) * 3
+    wshape = (cin, cout, 3, 3, 3) if mode == 2 else (cout, cin, 3, 3, 3)
+    wt = torch.randn(*wshape, generator=g) * (2.0 / (cin * 27)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    x64, w64 = x.double(), wt.double()
+    if mode == 2:
+        ref = F.conv_transpose3d(x64, w64, stride=2, padding=1, output_padding=1)
+    else:
+        ref = F.conv3d(x64, w64, stride=1 + mode, padding=1)
+    ref = F.relu(ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1))
+    skip = torch.randn(ref.shape, generator=g) if with_skip else None
+    if with_skip:
+        ref = ref + skip.double()
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    sk = skip.permute(0, 2, 3, 4, 1).contiguous().to(dev) if with_skip else None
+    packed = ops.pack_conv3d_weights_igemm(wt.to(dev), mode)
+    got, amax = ops.conv3d_bn_relu_igemm(xc, ops.absmax(xc), packed, cin, cout, scale.to(dev), shift.to(dev), mode, relu=True, skip=sk,
+                                         return_absmax=True)
+    y = got.permute(0, 4, 1, 2, 3).double().cpu()
+    sc = float(ref.abs().max())
+    assert float((y - ref).abs().max()) <= 3e-6 * sc
+    assert float(amax) == float(got.abs().max())
+    w32, _, _ = ops.pack_conv3d_weights(wt.to(dev), mode)
+    old = ops.conv3d_bn_relu(xc, w32, cin, cout, scale.to(dev), shift.to(dev), mode, relu=True, skip=sk)
+    assert float((old - got).abs().max()) <= 2e-5 * sc
+
+
+def test_conv3d_split_absmax_by_product(dev):
+    from robustmvd_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(1, 9, 11, 37, 32, generator=g) * 2).to(dev)
+    wt = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.05).to(dev)
+    sc, sh = (torch.rand(8, generator=g) + 0.5).to(dev), (torch.randn(8, generator=g) * 0.1).to(dev)
+    pk = ops.pack_conv3d_weights_split(wt)
+    for relu in (True, False):
+        want = ops.conv3d_bn_relu_split(x, pk, sc, sh, relu=relu)
+        got, amax = ops.conv3d_bn_relu_split(x, pk, sc, sh, relu=relu, return_absmax=True)
+        assert torch.equal(got, want) and float(amax) == float(want.abs().max()) > 0
