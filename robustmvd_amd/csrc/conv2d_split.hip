@@ -27,6 +27,7 @@
 // Transposed convolutions (4 x 4, stride 2, padding 1) run as four 2 x 2 stride-1 layers, one per output parity class.
 #include "mvd_common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 // knock-out builds for tools/ko_conv2d.sh (timing only, WRONG results): 1 stage only a workgroup's first chunk, 2 no MFMAs,
 // 4 weights loaded once, 8 activation fragments read once per step, 16 no stores
@@ -599,7 +600,13 @@ static bool c2_shape(int KH, int KW, int stride, int mode, int cin_pad, C2Shape*
 }
 
 // output channels per workgroup: the widest tile that does not leave most of it empty
-static int c2_bn(int cout) { return cout > 64 ? 128 : cout > 32 ? 64 : cout > 16 ? 32 : 16; }
+static int c2_bn(int cout) {
+    if (const char* e = exp_env("MVD_C2_BN")) {  // experiments library: forced channel tile (tools/sweep_conv2d_plan.py)
+        const int v = atoi(e);
+        if (v == 16 || v == 32 || v == 64 || v == 128) return v;
+    }
+    return cout > 64 ? 128 : cout > 32 ? 64 : cout > 16 ? 32 : 16;
+}
 static int c2_ntiles(int cout) { return (cout + c2_bn(cout) - 1) / c2_bn(cout) * (c2_bn(cout) / 16); }  // 16-channel tiles, whole workgroups
 static size_t c2_frag_bytes(const C2Shape& s, int cin_pad, int cout) {
     const size_t nchunks = (size_t)cin_pad / (8 * s.U8);
@@ -628,6 +635,10 @@ static C2Plan c2_plan(const C2Shape& s, int B, int Hi, int Wi, int cin_pad, int 
     q.ksplit = 1;  // a grid of 128+ workgroups runs as it is: the second pass would cost more than the idle CUs
     if (q.tiles < 128)
         while (q.tiles * q.ksplit < 320 && q.ksplit < 32 && q.nchunks / (q.ksplit * 2) >= 2) q.ksplit *= 2;
+    if (const char* e = exp_env("MVD_C2_KSPLIT")) {  // experiments library: forced split of the reduction
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32 && (v & (v - 1)) == 0 && v <= q.nchunks) q.ksplit = v;
+    }
     q.part_bytes = q.ksplit > 1 ? (size_t)q.ksplit * q.ncls * B * q.Ho * q.Wo * q.ncp * sizeof(float) : 0;
     return q;
 }

@@ -35,6 +35,7 @@ struct SweepParams {
     float corr_scale;    // 1/sqrt(C) for normalize="dim" (planesweep_corr.py:186), 1 otherwise
     int N, h, w, hs, ws, S, V;
     int out_ps;          // 0: outputs (N,S,h,w); > 0: pixel-major (N,h,w,S) with pixels out_ps floats apart (mvd_sweep_corr_nhwc_f32)
+    int tiles_x, per_xcd, total;  // 1-D grid: workgroup b works on unit (b % 8) * per_xcd + b / 8 of (view, batch, row, x tile)
 };
 
 constexpr int SWEEP_PX = 16;  // key pixels per workgroup
@@ -128,10 +129,17 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
     constexpr int C = 64 * NJ;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int y = blockIdx.y;
-    const int v = blockIdx.z % p.V;
-    const int n = blockIdx.z / p.V;
-    const int x0 = blockIdx.x * SWEEP_PX;
+    // Units in launch order.  (Experiments library, MVD_K1_XCD_ORDER: XCD k takes the k-th contiguous eighth of the units, so that an
+    // XCD's L2 sees neighbouring rows of one view only.  Measured 15 % SLOWER, 0.56 -> 0.65 ms: in launch order all XCDs sweep the
+    // same band of the source maps at the same time and share it through the Infinity Cache.)
+    int u = (int)(blockIdx.x % 8) * p.per_xcd + (int)(blockIdx.x / 8);
+    if (p.per_xcd == 0) u = blockIdx.x;
+    if (u >= p.total) return;
+    const int xt = u % p.tiles_x; u /= p.tiles_x;
+    const int y = u % p.h; u /= p.h;
+    const int v = u % p.V;
+    const int n = u / p.V;
+    const int x0 = xt * SWEEP_PX;
     const int h = p.h, w = p.w, hs = p.hs, ws = p.ws, S = p.S;
     const int W2 = ws + 3;  // zero-bordered source: pixel (yy, xx) at padded (yy+1, xx+1)
 
@@ -267,6 +275,224 @@ __global__ void __launch_bounds__(256) sweep_corr_kernel(SweepParams p) {
     }
 }
 
+// ---- K1, second form: every source pixel's dot product with the key feature is computed ONCE per 64 planes -------------------------
+// The kernel above takes the 2 x 2 cell of every distinct sampling position on its own: neighbouring cells along the epipolar line
+// share two of their four pixels, so nearly half of its gathers and dot products are repeats (profiles/k1_pmc.json: texture
+// addresser 65 % busy, 13.6 GB through the L1 for 184 MB of algorithmic input).  Here, per key pixel (one wave) and 64 planes:
+//   1. lanes = planes: sampling position, bilinear weights, mask, cell (as above; same arithmetic, same values);
+//   2. the distinct cells, in ray order, are compacted (ballot + prefix count) so that lanes = cells;
+//   3. every cell decides in closed form which of its 4 pixels the one or two cells before it already hold (a pixel lies in at most
+//      three consecutive cells of a monotone path; a longer chain just loads it again) and the new pixels get consecutive places
+//      in a list (wave prefix sum);
+//   4. the list is worked off 8 pixels per step: lane = (pixel l / 8, channel group l % 8), C / 8 channels per lane in 16-byte pieces
+//      128 bytes apart (each load instruction reads whole 128-byte lines: with C / 8 contiguous channels per lane it touched 64 lines
+//      and ran half as fast), 3 xor-steps finish a dot product; no per-cell control flow, loads one step ahead;
+//   5. lanes = planes again: 4 dot products by index, blended with the weights in grid_sample's order (nw, ne, sw, se).
+// Dot products are summed in a different order than above (rounding differs in the last bits); masks are identical.
+#define MVD_WAVE_LDS_SYNC()                                     \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+
+constexpr int SWEEP_SCR_INTS = 64 + 256 + 256 + 256;  // per wave: compacted cells | pixel list | 4 list places per cell | dot products
+
+template <int NCH>  // C = 8 * NCH
+__global__ void __launch_bounds__(256) sweep_corr_px_kernel(SweepParams p) {
+    extern __shared__ __attribute__((aligned(16))) float res[];  // [2][S][SWEEP_PX] | 4 x per-wave scratch
+    constexpr int C = 8 * NCH;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    int u = (int)(blockIdx.x % 8) * p.per_xcd + (int)(blockIdx.x / 8);
+    if (p.per_xcd == 0) u = blockIdx.x;
+    if (u >= p.total) return;
+    const int xt = u % p.tiles_x; u /= p.tiles_x;
+    const int y = u % p.h; u /= p.h;
+    const int v = u % p.V;
+    const int n = u / p.V;
+    const int x0 = xt * SWEEP_PX;
+    const int h = p.h, w = p.w, hs = p.hs, ws = p.ws, S = p.S;
+    const int W2 = ws + 3;
+
+    int* const scr = reinterpret_cast<int*>(res + 2 * S * SWEEP_PX) + wave * SWEEP_SCR_INTS;
+    int* const cellbuf = scr;
+    int* const pixlist = scr + 64;
+    int* const cellpix = scr + 64 + 256;
+    float* const dots = reinterpret_cast<float*>(scr + 64 + 512);
+
+    const Epi E = epipolar(p.K_key + n * 9, p.K_src.p[v] + n * 9, p.T.p[v] + n * 16, h, w, hs, ws);
+    const int cg = lane & 7, slot = lane >> 3;
+    // channels of lane group cg: 4 (cg + 8 j) .. + 3, j = 0 .. NCH / 4 - 1: load j of a pixel's 8 lanes is one contiguous 128-byte line
+    const float* __restrict__ src = p.src.p[v] + (size_t)n * (hs + 3) * W2 * C + cg * 4;
+    const float* __restrict__ invd = p.invd + (size_t)n * p.invd_stride;
+    const float inv_sqrt_c = p.corr_scale;
+    const float fws = (float)ws, fhs = (float)hs;
+    const float yc = (float)y + 0.5f;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (int pi = wave; pi < SWEEP_PX; pi += 4) {
+        const int x = x0 + pi;
+        if (x >= w) break;  // wave-uniform
+        const float xc = (float)x + 0.5f;
+        const float u_inf = (E.a * xc + E.b * yc) + E.c;
+        const float v_inf = (E.f * xc + E.g * yc) + E.h;
+        const float k_inf = (E.j * xc + E.k * yc) + E.l;
+        const float z_pole = -(E.m / k_inf);
+
+        float kf[NCH];
+        const float* kp = p.key + (((size_t)n * h + y) * w + x) * C + cg * 4;
+#pragma unroll
+        for (int j = 0; j < NCH; j += 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(kp + 8 * j);
+            kf[j] = t4.x; kf[j + 1] = t4.y; kf[j + 2] = t4.z; kf[j + 3] = t4.w;
+        }
+
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            // ---- 1. geometry of plane s0 + lane (the arithmetic of sweep_corr_kernel) ----
+            const int s = s0 + lane;
+            const bool live = s < S;
+            const int sc = live ? s : S - 1;
+            const float ds = p.invd_per_pixel ? p.invd[(((size_t)n * S + sc) * h + y) * w + x] : invd[sc];
+            const float den = k_inf + E.m * ds;
+            const float us = replace_nonfinite((u_inf + E.e * ds) / den);
+            const float vs = replace_nonfinite((v_inf + E.i * ds) / den);
+            const float zs = 1.0f / ds;
+            const bool visible = (zs > 0.f) && (((k_inf > 0.f) && (zs > z_pole)) || ((k_inf < 0.f) && (zs < z_pole)) ||
+                                               ((k_inf == 0.f) && (E.m > 0.f)));
+            const float ix = unnormalize_coord(2.0f * us / fws - 1.0f, fws);
+            const float iy = unnormalize_coord(2.0f * vs / fhs - 1.0f, fhs);
+            const Taps t = bilinear_taps(ix, iy, hs, ws);
+            const float mk = (t.inb < 0.9999f || !visible) ? 0.f : 1.f;
+            const int cx = (int)fminf(fmaxf(floorf(ix), -1.0f), (float)(ws - 1)) + 1;
+            const int cy = (int)fminf(fmaxf(floorf(iy), -1.0f), (float)(hs - 1)) + 1;
+            const int cell = live ? cy * W2 + cx : -1;
+
+            // ---- 2. distinct cells in ray order -> lanes ----
+            const int prev = __shfl_up(cell, 1);
+            const bool first = live && (lane == 0 || cell != prev);
+            const unsigned long long fb = __ballot(first);
+            const int ncell = __popcll(fb);
+            const int dci = __popcll(fb & lt_mask) + (first ? 1 : 0) - 1;  // index of this plane's cell among the distinct ones
+            if (first) cellbuf[dci] = cell;
+            MVD_WAVE_LDS_SYNC();
+            const bool isc = lane < ncell;
+            const int cj = isc ? cellbuf[lane] : 0x3fffffff;
+
+            // ---- 3. which pixels are new, and where every pixel's dot product will be ----
+            const int c1 = __shfl_up(cj, 1), c2 = __shfl_up(cj, 2), c3 = __shfl_up(cj, 3);
+            const int offs[4] = {0, 1, W2, W2 + 1};
+            auto in_cell = [W2](int d) { return d == 0 || d == 1 || d == W2 || d == W2 + 1; };
+            auto pos_of = [W2](int d) { return d == 0 ? 0 : d == 1 ? 1 : d == W2 ? 2 : 3; };
+            unsigned newmask = 0;
+            int owner[4], opos[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = cj + offs[k];
+                const bool in1 = lane >= 1 && in_cell(q - c1);
+                const bool in2 = in1 && lane >= 2 && in_cell(q - c2);
+                const bool in3 = in2 && lane >= 3 && in_cell(q - c3);
+                const bool isnew = !in1 || in3;  // (a chain of four cells through one pixel: load it again)
+                newmask |= isnew ? (1u << k) : 0u;
+                owner[k] = isnew ? 0 : in2 ? 2 : 1;
+                opos[k] = pos_of(in2 ? q - c2 : q - c1);
+            }
+            if (!isc) newmask = 0;
+            const int newcnt = __popc(newmask);
+            int incl = newcnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            const int base = incl - newcnt;
+            const int npix = __builtin_amdgcn_readlane(incl, 63);
+            const int b1 = __shfl_up(base, 1), b2 = __shfl_up(base, 2);
+            const unsigned m1 = (unsigned)__shfl_up((int)newmask, 1), m2 = (unsigned)__shfl_up((int)newmask, 2);
+            int idx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ob = owner[k] == 0 ? base : owner[k] == 1 ? b1 : b2;
+                const unsigned om = owner[k] == 0 ? newmask : owner[k] == 1 ? m1 : m2;
+                const int op = owner[k] == 0 ? k : opos[k];
+                idx[k] = ob + __popc(om & ((1u << op) - 1u));
+                if (isc && owner[k] == 0) pixlist[idx[k]] = cj + offs[k];
+            }
+            if (isc) *reinterpret_cast<int4*>(cellpix + 4 * lane) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            MVD_WAVE_LDS_SYNC();
+
+            // ---- 4. the dot products: 8 pixels per step, 8 lanes per pixel ----
+            const int nsteps = (npix + 7) >> 3;  // wave-uniform, >= 1
+            float ta[NCH], tb[NCH];
+            auto issue = [&](int i, float (&tt)[NCH]) {
+                const int li = min(8 * i + slot, npix - 1);
+                const float* __restrict__ sp = src + (size_t)pixlist[li] * C;
+#pragma unroll
+                for (int j = 0; j < NCH; j += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(sp + 8 * j);
+                    tt[j] = t4.x; tt[j + 1] = t4.y; tt[j + 2] = t4.z; tt[j + 3] = t4.w;
+                }
+            };
+            auto consume = [&](int i, const float (&tt)[NCH]) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NCH; j += 4) {
+                    a0 = fmaf(kf[j], tt[j], a0); a1 = fmaf(kf[j + 1], tt[j + 1], a1);
+                    a2 = fmaf(kf[j + 2], tt[j + 2], a2); a3 = fmaf(kf[j + 3], tt[j + 3], a3);
+                }
+                float d = (a0 + a1) + (a2 + a3);
+                d += __shfl_xor(d, 1);
+                d += __shfl_xor(d, 2);
+                d += __shfl_xor(d, 4);
+                if (cg == 0 && 8 * i + slot < npix) dots[8 * i + slot] = d;
+            };
+            issue(0, ta);
+            for (int i = 0; i < nsteps; i += 2) {  // wave-uniform
+                if (i + 1 < nsteps) issue(i + 1, tb);
+                consume(i, ta);
+                if (i + 1 >= nsteps) break;
+                if (i + 2 < nsteps) issue(i + 2, ta);
+                consume(i + 1, tb);
+            }
+            MVD_WAVE_LDS_SYNC();
+
+            // ---- 5. planes: blend the four dot products of the plane's cell ----
+            if (live) {
+                const int4 li = *reinterpret_cast<const int4*>(cellpix + 4 * dci);
+                const float d0 = dots[li.x], d1 = dots[li.y], d2 = dots[li.z], d3 = dots[li.w];
+                const float acc = fmaf(d3, t.w[3], fmaf(d2, t.w[2], fmaf(d1, t.w[1], d0 * t.w[0])));
+                res[s * SWEEP_PX + pi] = acc * inv_sqrt_c * mk;
+                res[(S + s) * SWEEP_PX + pi] = mk;
+            }
+            MVD_WAVE_LDS_SYNC();  // the scratch is rewritten by the next 64 planes
+        }
+    }
+    __syncthreads();
+    const int npx = min(SWEEP_PX, w - x0);
+    const size_t plane = (size_t)h * w;
+    if (p.out_ps > 0) {
+        float* __restrict__ cn = p.corr.p[v] + (((size_t)n * h + y) * w + x0) * p.out_ps;
+        float* __restrict__ mn = p.mask.p[v] + (((size_t)n * h + y) * w + x0) * p.out_ps;
+        for (int e = tid; e < S * SWEEP_PX; e += 256) {
+            const int px = e / S, s = e % S;
+            if (px < npx) {
+                cn[(size_t)px * p.out_ps + s] = res[s * SWEEP_PX + px];
+                mn[(size_t)px * p.out_ps + s] = res[(S + s) * SWEEP_PX + px];
+            }
+        }
+        return;
+    }
+    float* __restrict__ co = p.corr.p[v] + ((size_t)n * S * h + y) * w + x0;
+    float* __restrict__ mo = p.mask.p[v] + ((size_t)n * S * h + y) * w + x0;
+    for (int e = tid; e < S * SWEEP_PX; e += 256) {
+        const int s = e / SWEEP_PX, px = e % SWEEP_PX;
+        if (px < npx) {
+            co[(size_t)s * plane + px] = res[e];
+            mo[(size_t)s * plane + px] = res[S * SWEEP_PX + e];
+        }
+    }
+}
+
 // WarpOnlyCorr (planesweep_corr.py:107-140): the plane sweep without the correlation — the source features sampled at the
 // S positions of every key pixel, times the sampling mask.  Same grids and mask as sweep_corr_kernel; source features in the
 // caller's own (N,C,hs,ws) layout (one thread per (plane, key pixel) walks the channels, so neighbouring threads read
@@ -377,8 +603,37 @@ static int sweep_corr_run(const float* key_nhwc, const float* const* src_bordere
     p.corr_scale = corr_scale;
     p.N = N; p.h = h; p.w = w; p.hs = hs; p.ws = ws; p.S = S; p.V = V;
     p.out_ps = out_ps;
-    dim3 grid((unsigned)((w + mvd::SWEEP_PX - 1) / mvd::SWEEP_PX), (unsigned)h, (unsigned)(N * V));
+    p.tiles_x = (w + mvd::SWEEP_PX - 1) / mvd::SWEEP_PX;
+    const long long total = (long long)p.tiles_x * h * N * V;
+    if (total > 0x7fffff00LL) {
+        mvd::set_error("sweep_corr: %lld workgroups exceed the grid limit", total);
+        return MVD_ERR_INVALID_ARG;
+    }
+    p.total = (int)total;
+    p.per_xcd = mvd::exp_env("MVD_K1_XCD_ORDER") ? (p.total + 7) / 8 : 0;
+    dim3 grid((unsigned)(p.per_xcd ? 8 * p.per_xcd : p.total));
     mvd::timing_begin(st);
+    if (C <= 256 && !mvd::exp_env("MVD_K1_CELLS")) {  // every source pixel once per 64 planes (sweep_corr_px_kernel)
+        const size_t lds2 = lds + (size_t)4 * mvd::SWEEP_SCR_INTS * sizeof(int);
+        if (lds2 > 160 * 1024) {
+            mvd::set_error("sweep_corr: S=%d needs %zu B of LDS (> 160 KiB)", S, lds2);
+            return MVD_ERR_INVALID_ARG;
+        }
+        switch (C / 64) {
+#define MVD_CASE(NJ)                                                                                                  \
+    case NJ:                                                                                                          \
+        if (lds2 > 64 * 1024 &&                                                                                       \
+            hipFuncSetAttribute((const void*)mvd::sweep_corr_px_kernel<8 * NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds2) != hipSuccess)                                                             \
+            return mvd::launch_status("sweep_corr: LDS attribute");                                                   \
+        hipLaunchKernelGGL((mvd::sweep_corr_px_kernel<8 * NJ>), grid, dim3(256), lds2, st, p);                       \
+        break;
+            MVD_CASE(1) MVD_CASE(2) MVD_CASE(3) MVD_CASE(4)
+#undef MVD_CASE
+        }
+        mvd::timing_end(st);
+        return mvd::launch_status("sweep_corr");
+    }
     switch (C / 64) {
 #define MVD_CASE(NJ)                                                                                          \
     case NJ:                                                                                                  \

@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden
 import gen_common as gc
 import robustmvd_amd as R
 from robustmvd_amd import _lib as L
+if os.environ.get("MVD_ALT_LIB"):
+    L.use_experiments_library(os.environ["MVD_ALT_LIB"]).__enter__()
 CONFIGS = {1: (448, 640, 2), 2: (768, 1152, 4), 3: (896, 1216, 4)}
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
