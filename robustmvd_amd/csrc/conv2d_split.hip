@@ -202,9 +202,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
     constexpr int WN = 4 / WM, MTW = 16 / WM, STEPS = G::STEPS, PB = G::PB, PLANE = G::PLANE;
     // (Measured and dropped: the next chunk's global reads sent to a per-thread LDS scratch by LDS-DMA under this chunk's MFMAs.
     // vmcnt retires in order, so the weight fragments of the next K step then wait for those slow reads: 5-10 % slower.)
-    constexpr bool DB = U8 == 1 && !NCHW3;  // two patch buffers (below)
-    extern __shared__ __attribute__((aligned(16))) char patch[];  // (1 or 2) x [term][row][column parity][column / S][PB] | 4 floats
-    float* const wmax = reinterpret_cast<float*>(patch + (DB ? 4 : 2) * PLANE);
+    extern __shared__ __attribute__((aligned(16))) char patch[];  // [term][row][column parity][column / S][PB] | 4 floats
+    float* const wmax = reinterpret_cast<float*>(patch + 2 * PLANE);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int g = lane >> 4, px16 = lane & 15;
@@ -245,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
     };
 
     // staging items of this thread: global offset (floats, without the chunk's channel offset; -1 = outside the image) and LDS byte
-    int goff[G::NIT];  // floats from the start of the input image (plane); -1 = outside
+    long long goff[G::NIT];
     int loff[G::NIT];
 #pragma unroll
     for (int k = 0; k < G::NIT; ++k) {
@@ -256,10 +255,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
         const bool live = it < G::ITEMS;
         const bool inside = live && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         if constexpr (NCHW3) {
-            goff[k] = inside ? iy * p.Wi + ix : -1;
+            goff[k] = inside ? ((long long)b * 3 * p.Hi + iy) * p.Wi + ix : -1;
             loff[k] = live ? pix * PB : -1;
         } else {  // inside its input image; the image (plane) is the chunk's
-            goff[k] = inside ? (iy * p.Wi + ix) * p.xs + c8 * 8 : -1;
+            goff[k] = inside ? ((long long)iy * p.Wi + ix) * p.xs + c8 * 8 : -1;
             loff[k] = live ? ((py * S + pxx % S) * G::PWS + pxx / S) * PB + c8 * 16 : -1;
         }
     }
@@ -302,43 +301,48 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
         }
     }
 
-    // staging of items [k0, k1) of this thread: global fp32 -> registers, and registers -> two fp16 terms -> LDS patch `dst`
-    auto chunk_src = [&](int chunk, bool& zlive) -> const float* {
-        const int kd = chunk / p.nchunks_c, zi = od * p.SD - p.pad_d + kd;  // the input plane of this chunk (0 for a 2-D layer)
-        zlive = zi >= 0 && zi < p.Di;
-        return p.x + ((size_t)bb * p.Di + (zlive ? zi : 0)) * p.Hi * p.Wi * p.xs + (size_t)(chunk - kd * p.nchunks_c) * G::CC;
-    };
-    auto load_item = [&](const float* xim, bool zlive, int k, c2f4& v0, c2f4& v1) {
-        v0 = c2f4{0, 0, 0, 0};
-        v1 = c2f4{0, 0, 0, 0};
-        if (goff[k] >= 0 && zlive) {
-            if constexpr (NCHW3) {
-                const size_t pl = (size_t)p.Hi * p.Wi;
-                const float* im = p.x + (size_t)b * 3 * pl + goff[k];
-                v0[0] = im[0]; v0[1] = im[pl]; v0[2] = im[2 * pl];
-            } else {
-                v0 = *reinterpret_cast<const c2f4*>(xim + goff[k]);
-                v1 = *reinterpret_cast<const c2f4*>(xim + goff[k] + 4);
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        // ---- stage the chunk's patch: global fp32 -> two fp16 terms -> LDS -------------------------------------------------------
+        if (!(C2_KO & 1) || chunk == c_begin) {
+            c2f4 v0[G::NIT], v1[G::NIT];
+            const int kd = chunk / p.nchunks_c, zi = od * p.SD - p.pad_d + kd;  // the input plane of this chunk (0 for a 2-D layer)
+            const bool zlive = zi >= 0 && zi < p.Di;
+            const float* xim = p.x + ((size_t)bb * p.Di + (zlive ? zi : 0)) * p.Hi * p.Wi * p.xs + (size_t)(chunk - kd * p.nchunks_c) * G::CC;
+#pragma unroll
+            for (int k = 0; k < G::NIT; ++k) {
+                v0[k] = c2f4{0, 0, 0, 0};
+                v1[k] = c2f4{0, 0, 0, 0};
+                if (goff[k] >= 0 && zlive) {
+                    if constexpr (NCHW3) {
+                        const size_t pl = (size_t)p.Hi * p.Wi;
+                        v0[k][0] = p.x[goff[k]]; v0[k][1] = p.x[goff[k] + pl]; v0[k][2] = p.x[goff[k] + 2 * pl];
+                    } else {
+                        v0[k] = *reinterpret_cast<const c2f4*>(xim + goff[k]);
+                        v1[k] = *reinterpret_cast<const c2f4*>(xim + goff[k] + 4);
+                    }
+                }
             }
+            __syncthreads();  // every wave has finished reading the previous chunk's patch
+#pragma unroll
+            for (int k = 0; k < G::NIT; ++k) {
+                if (loff[k] < 0) continue;
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                split2(v0[k][0], v0[k][1], h0, l0);
+                split2(v0[k][2], v0[k][3], h1, l1);
+                if constexpr (NCHW3) {
+                    *reinterpret_cast<unsigned long long*>(patch + loff[k]) = (unsigned long long)h0 | ((unsigned long long)h1 << 32);
+                    *reinterpret_cast<unsigned long long*>(patch + loff[k] + PLANE) = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
+                    continue;
+                }
+                split2(v1[k][0], v1[k][1], h2, l2);
+                split2(v1[k][2], v1[k][3], h3, l3);
+                *reinterpret_cast<c2u4*>(patch + loff[k]) = c2u4{h0, h1, h2, h3};
+                *reinterpret_cast<c2u4*>(patch + loff[k] + PLANE) = c2u4{l0, l1, l2, l3};
+            }
+            __syncthreads();
         }
-    };
-    auto write_item = [&](char* dst, int k, const c2f4& v0, const c2f4& v1) {
-        if (loff[k] < 0) return;
-        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-        split2(v0[0], v0[1], h0, l0);
-        split2(v0[2], v0[3], h1, l1);
-        if constexpr (NCHW3) {
-            *reinterpret_cast<unsigned long long*>(dst + loff[k]) = (unsigned long long)h0 | ((unsigned long long)h1 << 32);
-            *reinterpret_cast<unsigned long long*>(dst + loff[k] + PLANE) = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
-            return;
-        }
-        split2(v1[0], v1[1], h2, l2);
-        split2(v1[2], v1[3], h3, l3);
-        *reinterpret_cast<c2u4*>(dst + loff[k]) = c2u4{h0, h1, h2, h3};
-        *reinterpret_cast<c2u4*>(dst + loff[k] + PLANE) = c2u4{l0, l1, l2, l3};
-    };
-    // K steps of one chunk on patch `cur`; `between(s)` runs before and `after(s)` after the MFMAs of step s
-    auto k_steps = [&](const char* cur, auto&& before, auto&& after) {
+
+        // ---- K steps: activation fragments one pixel row ahead, weights one step ahead ---------------------------------------------
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             c2h8 nh[NTW], nl[NTW];
@@ -355,9 +359,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
                 }
                 wc += 2048;
             }
-            before(s);
-            __builtin_amdgcn_sched_barrier(0);
-            const char* a = cur + tapoff[s];
+            const char* a = patch + tapoff[s];
             c2h8 xh = *reinterpret_cast<const c2h8*>(a), xl = *reinterpret_cast<const c2h8*>(a + PLANE);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
@@ -380,64 +382,6 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
             }
 #pragma unroll
             for (int t = 0; t < NTW; ++t) { wh[t] = nh[t]; wl[t] = nl[t]; }
-            after(s);
-        }
-    };
-
-    if constexpr (DB) {
-        // 8-channel chunks are short (3 .. 7 K steps): two patch buffers, the next chunk staged while this one is multiplied.  Its items
-        // are dealt over the steps: requested before the MFMAs of step s, converted and written before those of step s + 1 (a full step
-        // of matrix work hides the read); one barrier per chunk.  (Staged between the chunks, with two barriers, the global latency of
-        // every chunk was exposed: 77 of the 355 us of the 5x5 layer, tools/ko_conv2d.sh.)
-        constexpr int NL = STEPS - 1, IPS = (G::NIT + NL - 1) / NL;  // load steps 0 .. NL-1, items per load step
-        static_assert(NL >= 1 && IPS * NL >= G::NIT, "staging schedule");
-        if (c_begin < c_end) {
-            bool zl;
-            const float* xim = chunk_src(c_begin, zl);
-            c2f4 v0[G::NIT], v1[G::NIT];
-#pragma unroll
-            for (int k = 0; k < G::NIT; ++k) load_item(xim, zl, k, v0[k], v1[k]);
-#pragma unroll
-            for (int k = 0; k < G::NIT; ++k) write_item(patch, k, v0[k], v1[k]);
-            __syncthreads();
-        }
-        for (int chunk = c_begin; chunk < c_end; ++chunk) {
-            const int bsel = (chunk - c_begin) & 1;
-            const char* cur = patch + bsel * (2 * PLANE);
-            char* nxt = patch + (bsel ^ 1) * (2 * PLANE);
-            const bool has_next = chunk + 1 < c_end && !(C2_KO & 1);
-            bool zl = false;
-            const float* xim = has_next ? chunk_src(chunk + 1, zl) : p.x;
-            c2f4 sv0[IPS], sv1[IPS];  // one set: the items of step s - 1 are written before those of step s are requested
-            k_steps(cur,
-                    [&](int s) {
-                        if (!has_next) return;
-                        if (s >= 1 && s - 1 < NL)
-#pragma unroll
-                            for (int i = 0; i < IPS; ++i)
-                                if ((s - 1) * IPS + i < G::NIT) write_item(nxt, (s - 1) * IPS + i, sv0[i], sv1[i]);
-                        if (s < NL)
-#pragma unroll
-                            for (int i = 0; i < IPS; ++i)
-                                if (s * IPS + i < G::NIT) load_item(xim, zl, s * IPS + i, sv0[i], sv1[i]);
-                    },
-                    [](int) {});
-            __syncthreads();  // the next patch is complete, this one free
-        }
-    } else {
-        for (int chunk = c_begin; chunk < c_end; ++chunk) {
-            if (!(C2_KO & 1) || chunk == c_begin) {
-                bool zl;
-                const float* xim = chunk_src(chunk, zl);
-                c2f4 v0[G::NIT], v1[G::NIT];
-#pragma unroll
-                for (int k = 0; k < G::NIT; ++k) load_item(xim, zl, k, v0[k], v1[k]);
-                __syncthreads();  // every wave has finished reading the previous chunk's patch
-#pragma unroll
-                for (int k = 0; k < G::NIT; ++k) write_item(patch, k, v0[k], v1[k]);
-                __syncthreads();
-            }
-            k_steps(patch, [](int) {}, [](int) {});
         }
     }
 
@@ -703,7 +647,7 @@ template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
 static int c2_launch(const C2Params& p, long long nblk, hipStream_t st) {
     using G = C2Geom<KH, KW, S, U8, NCHW3>;
     auto kern = conv2d_split_kernel<KH, KW, S, U8, WM, NTW, NCHW3>;
-    constexpr int lds = (U8 == 1 && !NCHW3 ? 4 : 2) * G::PLANE + 16;
+    constexpr int lds = 2 * G::PLANE + 16;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return launch_status("conv2d_split: LDS attribute");
