@@ -105,11 +105,12 @@ int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, c
 /* K1 on the layouts the kernel works in, without the re-packing launches: feat_key (N,h,w,C) channel-last, feat_src[v] zero-bordered
  * channel-last (N,hs+3,ws+3,C) with the map at rows/columns 1.. (what mvd_conv2d_split_f32 writes with its row/image strides),
  * outputs pixel-major: corr_out[v][(n h w + pixel) * out_pixel_stride + s] (and mask_out alike), i.e. (N,h,w,S) maps that the
- * 2-D convolutions behind the sweep read as S channels.  No workspace. */
+ * 2-D convolutions behind the sweep read as S channels.  No workspace.  corr_absmax: NULL, or a device float that receives
+ * max |corr| over all views by atomic maximum (the caller zeroes it; C <= 256). */
 int mvd_sweep_corr_nhwc_f32(const float* feat_key, const float* const* feat_src, const float* K_key, const float* const* K_src,
                             const float* const* T_src2key, const float* invdepths, int invdepth_mode, float corr_scale, int N, int C,
                             int h, int w, int hs, int ws, int S, int V, float* const* corr_out, float* const* mask_out,
-                            int out_pixel_stride, mvd_stream_t stream);
+                            int out_pixel_stride, float* corr_absmax, mvd_stream_t stream);
 
 /* The sweep of PlanesweepCorrelation(warp_only=True) — replaces WarpOnlyCorr.forward + warp_multi
  *   rmvd/models/blocks/planesweep_corr.py:107-140, 13-45 (reached through correlate(), :514-521):

@@ -46,7 +46,7 @@ SIGNATURES = {
     "mvd_sweep_corr_ex_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, ctypes.c_float] + [_i] * 8
                               + [_pp, _pp, ctypes.c_void_p, _sz, ctypes.c_void_p]),
     "mvd_sweep_corr_nhwc_f32": (_i, [_c_float_p, _pp, _c_float_p, _pp, _pp, _c_float_p, _i, ctypes.c_float] + [_i] * 8
-                                + [_pp, _pp, _i, ctypes.c_void_p]),
+                                + [_pp, _pp, _i, _c_float_p, ctypes.c_void_p]),
     "mvd_fuse_views_nhwc_f32": (_i, [_pp, _pp, _pp] + [_i] * 6 + [_c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p]),
     "mvd_upsample2x_nhwc_f32": (_i, [_c_float_p, _c_float_p, _c_float_p] + [_i] * 5 + [ctypes.c_void_p]),
     "mvd_sweep_warp_f32": (_i, [_pp, _c_float_p, _pp, _pp, _c_float_p] + [_i] * 10 + [_pp, _pp, ctypes.c_void_p]),

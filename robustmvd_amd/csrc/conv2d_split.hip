@@ -422,6 +422,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
 }
 
 // split K, second kernel: partial sums added in the fixed order ks = 0, 1, ...; then the same epilogue.  One thread = 4 channels.
+// (Measured and dropped: no second launch, the workgroup that draws the last ticket of a tile adds the partial sums up.  The
+// agent-scope release every workgroup then needs before its ticket writes back its XCD's whole L2: the split layers ran 2-5x slower.)
 __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
     __shared__ float wmax[4];
     const long long npix = (long long)p.B * p.Ho * p.Wo;

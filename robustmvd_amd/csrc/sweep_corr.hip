@@ -35,6 +35,7 @@ struct SweepParams {
     float corr_scale;    // 1/sqrt(C) for normalize="dim" (planesweep_corr.py:186), 1 otherwise
     int N, h, w, hs, ws, S, V;
     int out_ps;          // 0: outputs (N,S,h,w); > 0: pixel-major (N,h,w,S) with pixels out_ps floats apart (mvd_sweep_corr_nhwc_f32)
+    float* amax;         // optional: max |corr| over all views' outputs, raised atomically (pixel-major entry point; caller zeroes)
     int tiles_x, per_xcd, total;  // 1-D grid: workgroup b works on unit (b % 8) * per_xcd + b / 8 of (view, batch, row, x tile)
 };
 
@@ -473,12 +474,19 @@ __global__ void __launch_bounds__(256) sweep_corr_px_kernel(SweepParams p) {
     if (p.out_ps > 0) {
         float* __restrict__ cn = p.corr.p[v] + (((size_t)n * h + y) * w + x0) * p.out_ps;
         float* __restrict__ mn = p.mask.p[v] + (((size_t)n * h + y) * w + x0) * p.out_ps;
+        float am = 0.f;
         for (int e = tid; e < S * SWEEP_PX; e += 256) {
             const int px = e / S, s = e % S;
             if (px < npx) {
-                cn[(size_t)px * p.out_ps + s] = res[s * SWEEP_PX + px];
+                const float c = res[s * SWEEP_PX + px];
+                cn[(size_t)px * p.out_ps + s] = c;
                 mn[(size_t)px * p.out_ps + s] = res[(S + s) * SWEEP_PX + px];
+                am = fmaxf(am, finite_abs_or_zero(c));
             }
+        }
+        if (p.amax) {  // what the fusion block's first convolution scales its activations by; a wave rarely has to raise the slot
+            for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+            if (lane == 0) raise_absmax(p.amax, am);
         }
         return;
     }
@@ -585,7 +593,8 @@ int mvd_sweep_corr_f32(const float* feat_key, const float* const* feat_src, cons
 
 static int sweep_corr_run(const float* key_nhwc, const float* const* src_bordered, const float* K_key, const float* const* K_src,
                           const float* const* T_src2key, const float* invdepths, int invdepth_mode, float corr_scale, int N, int C, int h,
-                          int w, int hs, int ws, int S, int V, float* const* corr_out, float* const* mask_out, int out_ps, hipStream_t st) {
+                          int w, int hs, int ws, int S, int V, float* const* corr_out, float* const* mask_out, int out_ps, float* amax,
+                          hipStream_t st) {
     const size_t lds = (size_t)2 * S * mvd::SWEEP_PX * sizeof(float);
     mvd::SweepParams p{};
     p.key = key_nhwc;
@@ -603,6 +612,7 @@ static int sweep_corr_run(const float* key_nhwc, const float* const* src_bordere
     p.corr_scale = corr_scale;
     p.N = N; p.h = h; p.w = w; p.hs = hs; p.ws = ws; p.S = S; p.V = V;
     p.out_ps = out_ps;
+    p.amax = amax;
     p.tiles_x = (w + mvd::SWEEP_PX - 1) / mvd::SWEEP_PX;
     const long long total = (long long)p.tiles_x * h * N * V;
     if (total > 0x7fffff00LL) {
@@ -693,20 +703,21 @@ int mvd_sweep_corr_ex_f32(const float* feat_key, const float* const* feat_src, c
         if (rc) return rc;
         srcs[v] = wsp + v * per;
     }
-    return sweep_corr_run(key, srcs, K_key, K_src, T_src2key, invdepths, invdepth_mode, corr_scale, N, C, h, w, hs, ws, S, V, corr_out, mask_out, 0, st);
+    return sweep_corr_run(key, srcs, K_key, K_src, T_src2key, invdepths, invdepth_mode, corr_scale, N, C, h, w, hs, ws, S, V, corr_out, mask_out, 0, nullptr, st);
 }
 
 int mvd_sweep_corr_nhwc_f32(const float* feat_key, const float* const* feat_src, const float* K_key, const float* const* K_src,
                             const float* const* T_src2key, const float* invdepths, int invdepth_mode, float corr_scale, int N, int C,
                             int h, int w, int hs, int ws, int S, int V, float* const* corr_out, float* const* mask_out,
-                            int out_pixel_stride, mvd_stream_t stream) {
+                            int out_pixel_stride, float* corr_absmax, mvd_stream_t stream) {
     int rc = sweep_corr_check(feat_key, feat_src, K_key, K_src, T_src2key, invdepths, invdepth_mode, N, C, h, w, hs, ws, S, V, corr_out, mask_out);
     if (rc) return rc;
     MVD_REQUIRE(out_pixel_stride >= S, "sweep_corr_nhwc: output pixel stride %d below S=%d", out_pixel_stride, S);
     for (int v = 0; v < V; ++v)
         MVD_REQUIRE(feat_src[v] && K_src[v] && T_src2key[v] && corr_out[v] && mask_out[v], "sweep_corr: NULL view %d", v);
+    MVD_REQUIRE(!corr_absmax || C <= 256, "sweep_corr_nhwc: corr_absmax is built for C <= 256");
     return sweep_corr_run(feat_key, feat_src, K_key, K_src, T_src2key, invdepths, invdepth_mode, corr_scale, N, C, h, w, hs, ws, S, V, corr_out,
-                          mask_out, out_pixel_stride, (hipStream_t)stream);
+                          mask_out, out_pixel_stride, corr_absmax, (hipStream_t)stream);
 }
 int mvd_sweep_warp_f32(const float* const* feat_src, const float* K_key, const float* const* K_src,
                        const float* const* T_src2key, const float* invdepths, int invdepth_mode, int normalize_after, int N,

@@ -124,13 +124,15 @@ class DispnetEngine:
         inv = m.corr_block.warm(sampling_type="linear_invdepth", device=dev, **m.SWEEP)  # (1,S), cached on the device
         if V == 1:  # LearnedFusion passes a single view through (learned_fusion.py:28-30)
             mask = e(n, h8, w8, 288)[..., 32:]  # the pixel stride of its correlation map
-            ops.sweep_corr_nhwc(c3k, [c3s], intrinsics_key, intrinsics_source, source_to_key, inv, [merged[..., 32:]], [mask])
-            torch.maximum(a_merged, ops.absmax(merged), out=a_merged)
+            ops.sweep_corr_nhwc(c3k, [c3s], intrinsics_key, intrinsics_source, source_to_key, inv, [merged[..., 32:]], [mask],
+                                corr_absmax=a_merged)
         else:
             corr, mask = e(V * n, h8, w8, S), e(V * n, h8, w8, S)
             views = lambda t: [t[v * n:(v + 1) * n] for v in range(V)]
-            ops.sweep_corr_nhwc(c3k, views(c3s), intrinsics_key, intrinsics_source, source_to_key, inv, views(corr), views(mask))
-            mid, a_mid = layer("score3", corr, ops.absmax(corr), act=2)
+            a_corr = slot()
+            ops.sweep_corr_nhwc(c3k, views(c3s), intrinsics_key, intrinsics_source, source_to_key, inv, views(corr), views(mask),
+                                corr_absmax=a_corr)
+            mid, a_mid = layer("score3", corr, a_corr, act=2)
             scores = ops.conv2d_split(mid, a_mid, w["score1"], act=0)
             del mid
             ops.fuse_views_nhwc(views(corr), views(mask), views(scores), merged[..., 32:], out_absmax=a_merged)

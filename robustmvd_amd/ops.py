@@ -694,9 +694,10 @@ def upsample2x_into(x, out, out_absmax=None):
 
 
 @inference_only
-def sweep_corr_nhwc(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths, corrs, masks, corr_scale=None):
+def sweep_corr_nhwc(feat_key, feat_sources, K_key, K_sources, T_src2key, invdepths, corrs, masks, corr_scale=None, corr_absmax=None):
     """K1 on its working layouts (mvd_sweep_corr_nhwc_f32): feat_key (N,h,w,C) channel-last; feat_sources V x zero-bordered
-    channel-last (N,hs+3,ws+3,C); corrs, masks: V x pixel-major destinations (N,h,w,S) (channel slices allowed), filled in place."""
+    channel-last (N,hs+3,ws+3,C); corrs, masks: V x pixel-major destinations (N,h,w,S) (channel slices allowed), filled in place.
+    corr_absmax: one-element device tensor raised to max |corr| over all views (zero it first), or None."""
     lib = L.load()
     fk = L.as_f32(feat_key, "feat_key")
     N, h, w, C = fk.shape
@@ -728,9 +729,10 @@ def sweep_corr_nhwc(feat_key, feat_sources, K_key, K_sources, T_src2key, invdept
     a_T, k3 = L.ptr_array(Ts)
     a_c, k4 = L.ptr_array(list(corrs))
     a_m, k5 = L.ptr_array(list(masks))
+    cam = None if corr_absmax is None else L.as_f32(corr_absmax, "corr_absmax", (1,), dev)
     with torch.cuda.device(dev):
         rc = lib.mvd_sweep_corr_nhwc_f32(L.ptr(fk), a_src, L.ptr(Kk), a_K, a_T, L.ptr(inv), mode, scale, N, C, h, w, hs, ws, S, V,
-                                         a_c, a_m, ps, L.stream_of(fk))
+                                         a_c, a_m, ps, L.ptr(cam), L.stream_of(fk))
     L.check(rc, "mvd_sweep_corr_nhwc_f32")
     return corrs, masks
 

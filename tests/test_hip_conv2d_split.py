@@ -170,7 +170,9 @@ def test_sweep_and_fusion_on_channel_last_layouts_equal_the_planar_entry_points(
     big_c, big_m = torch.zeros(V, N, h, w, S + 8, device=dev), torch.zeros(V, N, h, w, S + 8, device=dev)
     c2 = [big_c[v, ..., 8:] for v in range(V)]
     m2 = [big_m[v, ..., 8:] for v in range(V)]
-    ops.sweep_corr_nhwc(key_cl, bordered, *args, c2, m2)
+    cam = torch.zeros(1, device=dev)
+    ops.sweep_corr_nhwc(key_cl, bordered, *args, c2, m2, corr_absmax=cam)
+    assert float(cam) == max(float(c.abs().max()) for c in corrs)
     for v in range(V):
         assert torch.equal(c2[v].permute(0, 3, 1, 2), corrs[v]) and torch.equal(m2[v].permute(0, 3, 1, 2), masks[v])
     scores = [torch.randn(N, 1, h, w, device=dev) for _ in range(V)]
