@@ -456,3 +456,41 @@ def test_pinned_uploader_consumed_on_another_stream(dev):
     for i, s_ in enumerate(sums):
         want = sum(float(np.asarray(im, np.float64).sum()) for im in frames[i])
         assert abs(float(s_) - want) <= 1e-9 * abs(want)
+
+
+def test_robustmvd_engine_matches_vendor_library_form_batch_two_three_sources(dev):
+    """The engine's 2-D CNN (dispnet_engine.py) against the layer-by-layer form on the vendor library's convolutions: batch of 2,
+    3 source views, key view in the middle; and the cases that must fall back to the layer-by-layer form."""
+    import robustmvd_amd as R
+    torch.manual_seed(11)
+    eng = R.RobustMVD().eval().to(dev)
+    lib = R.RobustMVD(engine_dispnet=False).eval().to(dev)
+    lib.load_state_dict(eng.state_dict())
+    n, H, W = 2, 128, 192
+    rng = np.random.default_rng(5)
+    images = [torch.from_numpy(rng.uniform(-0.4, 0.6, (n, 3, H, W)).astype(np.float32)).to(dev) for _ in range(4)]
+    K = gc.synthetic_intrinsics(H, W) / np.array([[W] * 3, [H] * 3, [1.0] * 3], np.float32)
+    intr = [torch.from_numpy(np.stack([K] * n).astype(np.float32)).to(dev) for _ in range(4)]
+    poses = [torch.from_numpy(np.stack([gc.synthetic_pose(rng) for _ in range(n)])).to(dev) for _ in range(4)]
+    poses[2] = torch.eye(4, device=dev).repeat(n, 1, 1)
+    key = torch.tensor([2, 2])
+    with torch.no_grad():
+        pe, ae = eng(images=images, poses=poses, intrinsics=intr, keyview_idx=key)
+        pl, al = lib(images=images, poses=poses, intrinsics=intr, keyview_idx=key)
+    assert eng._engine is not None and lib._engine is None
+    assert pe["depth"].shape == pl["depth"].shape == (n, 1, H // 2, W // 2)
+    for k in ("invdepth", "invdepth_log_b", "invdepth_uncertainty"):
+        torch.testing.assert_close(ae[k], al[k], atol=3e-5, rtol=3e-5)
+    for a_, b_ in zip(ae["invdepths_all"], al["invdepths_all"]):
+        torch.testing.assert_close(a_, b_, atol=1e-4, rtol=1e-4)
+    # one source view (LearnedFusion passes it through)
+    with torch.no_grad():
+        p1, a1 = eng(images=images[1:3], poses=poses[1:3], intrinsics=intr[1:3], keyview_idx=torch.tensor([1, 1]))
+        p2, a2 = lib(images=images[1:3], poses=poses[1:3], intrinsics=intr[1:3], keyview_idx=torch.tensor([1, 1]))
+    torch.testing.assert_close(a1["invdepth"], a2["invdepth"], atol=3e-5, rtol=3e-5)
+    # under autograd the layer-by-layer form runs (the engine is inference only)
+    eng._engine = None
+    p3, a3 = eng(images=images, poses=poses, intrinsics=intr, keyview_idx=key)
+    p4, a4 = lib(images=images, poses=poses, intrinsics=intr, keyview_idx=key)
+    assert eng._engine is None and a3["invdepth"].requires_grad
+    torch.testing.assert_close(a3["invdepth"], a4["invdepth"], atol=1e-5, rtol=1e-5)
