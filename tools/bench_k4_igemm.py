@@ -6,6 +6,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from robustmvd_amd import ops, _lib as L
+if os.environ.get("MVD_ALT_LIB"):
+    L.use_experiments_library(os.environ["MVD_ALT_LIB"]).__enter__()
+ONLY = os.environ.get("MVD_K4_ONLY", "").split(",") if os.environ.get("MVD_K4_ONLY") else None
 D, h, w = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 192, 288)
 dev = torch.device("cuda:0")
 LAYERS = [("conv1", 1, 8, 16, 1), ("conv3", 1, 16, 32, 2), ("conv5", 1, 32, 64, 4), ("conv6", 0, 64, 64, 8), ("conv7", 2, 64, 32, 8),
@@ -24,6 +27,8 @@ def timeit(fn, n=10):
 
 
 for name, mode, cin, cout, div in LAYERS:
+    if ONLY and name not in ONLY:
+        continue
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.rand(1, D // div, h // div, w // div, cin, generator=g).to(dev)
     wshape = (cin, cout, 3, 3, 3) if mode == 2 else (cout, cin, 3, 3, 3)
