@@ -360,13 +360,20 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
                 wc += 2048;
             }
             const char* a = patch + tapoff[s];
+            // activation fragments TWO pixel rows ahead (one row = 3 NTW MFMAs = 48 .. 96 clocks: less than a conflicted LDS read)
             c2h8 xh = *reinterpret_cast<const c2h8*>(a), xl = *reinterpret_cast<const c2h8*>(a + PLANE);
+            c2h8 yh = xh, yl = xl;
+            if (MTW > 1) {
+                yh = *reinterpret_cast<const c2h8*>(a + G::ROWB);
+                yl = *reinterpret_cast<const c2h8*>(a + G::ROWB + PLANE);
+            }
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const c2h8 ch = xh, cl = xl;
-                if (m + 1 < MTW && !(C2_KO & 8)) {
-                    xh = *reinterpret_cast<const c2h8*>(a + (m + 1) * G::ROWB);
-                    xl = *reinterpret_cast<const c2h8*>(a + (m + 1) * G::ROWB + PLANE);
+                xh = yh; xl = yl;
+                if (m + 2 < MTW && !(C2_KO & 8)) {
+                    yh = *reinterpret_cast<const c2h8*>(a + (m + 2) * G::ROWB);
+                    yl = *reinterpret_cast<const c2h8*>(a + (m + 2) * G::ROWB + PLANE);
                 }
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
