@@ -30,6 +30,8 @@ class DispnetEngine:
         self._key = None
         self.w = None
         self._bufs = {}
+        self._sides = {}
+        self.side_stream = True  # key view's encoder chain beside the source views' (tools/path_a_engine.py measures both)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _prepare(self):
@@ -77,6 +79,14 @@ class DispnetEngine:
                 "slots": z(40)}
         return b
 
+    def _side_stream(self, dev, main):
+        """One side stream per stream the model is called on (FramePipeline calls it on two)."""
+        key = (str(dev), main.cuda_stream)
+        st = self._sides.get(key)
+        if st is None:
+            st = self._sides[key] = torch.cuda.Stream(device=dev)
+        return st
+
     # ------------------------------------------------------------------------------------------------------------------
     def forward(self, image_key, images_source, intrinsics_key, intrinsics_source, source_to_key):
         """image_key (n,3,H,W), images_source V x (n,3,H,W) (all one size, H and W multiples of 64) -> the decoder's dict of
@@ -102,13 +112,21 @@ class DispnetEngine:
             return ops.conv2d_split(x, ax, w[name], out_absmax=a, **kw), a
 
         # ---- encoder: key view into the decoder's concat buffers, source views as one batch into K1's bordered maps -------
+        # The key view's chain (4 launches on ONE image: they fill half the chip) runs on a side stream beside the source views'.
         cat5, cat4 = bufs["cat5"], bufs["cat4"]
-        a_cat5, a_cat4 = slot(), slot()
-        ops.conv2d_split(image_key, ops.absmax(image_key), w["conv1"], out=cat5[..., :64], out_absmax=a_cat5)
-        ops.conv2d_split(cat5[..., :64], a_cat5, w["conv2"], out=cat4[..., :128], out_absmax=a_cat4)
-        c3k, a_c3k = e(n, h8, w8, 256), slot()
-        # (conv2 reads before the decoder adds to the slots: every later writer only raises them, which stays a valid bound)
-        ops.conv2d_split(cat4[..., :128], a_cat4, w["conv3"], out=c3k, out_absmax=a_c3k)
+        a_cat5, a_cat4, a_c3k, a_merged = slot(), slot(), slot(), slot()
+        c3k, merged = e(n, h8, w8, 256), e(n, h8, w8, 288)
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev, main) if self.side_stream else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            a_key = ops.absmax(image_key)
+            a_key.record_stream(main)
+            ops.conv2d_split(image_key, a_key, w["conv1"], out=cat5[..., :64], out_absmax=a_cat5)
+            ops.conv2d_split(cat5[..., :64], a_cat5, w["conv2"], out=cat4[..., :128], out_absmax=a_cat4)
+            # (conv2 reads before the decoder adds to the slots: every later writer only raises them, which stays a valid bound)
+            ops.conv2d_split(cat4[..., :128], a_cat4, w["conv3"], out=c3k, out_absmax=a_c3k)
+            ops.conv2d_split(c3k, a_c3k, w["conv_redir"], out=merged[..., :32], out_absmax=a_merged)
         # (one launch over the concatenated source images: per-view launches of this layer measured 2.2x slower, tail effects)
         src = torch.cat(list(images_source), 0) if V > 1 else images_source[0]
         s1, a1 = layer("conv1", src, ops.absmax(src))
@@ -117,10 +135,9 @@ class DispnetEngine:
         c3s = bufs["c3s"]
         ops.conv2d_split(s2, a2, w["conv3"], out=c3s[:, 1:h8 + 1, 1:w8 + 1, :])
         del s2
+        main.wait_stream(side)
 
-        # ---- context, sweep, learned fusion ---------------------------------------------------------------------------------
-        merged, a_merged = e(n, h8, w8, 288), slot()
-        ops.conv2d_split(c3k, a_c3k, w["conv_redir"], out=merged[..., :32], out_absmax=a_merged)
+        # ---- sweep, learned fusion -------------------------------------------------------------------------------------------------
         inv = m.corr_block.warm(sampling_type="linear_invdepth", device=dev, **m.SWEEP)  # (1,S), cached on the device
         if V == 1:  # LearnedFusion passes a single view through (learned_fusion.py:28-30)
             mask = e(n, h8, w8, 288)[..., 32:]  # the pixel stride of its correlation map

@@ -32,6 +32,10 @@ def timeit(m, label):
 
 assert model.engine_dispnet
 a = timeit(model, "engine 2-D CNN (default)")
+model._engine.side_stream = False
+timeit(model, "engine, key encoder in line")
+model._engine.side_stream = True
+timeit(model, "engine 2-D CNN (default) again")
 ref = R.RobustMVD(engine_dispnet=False).eval().to(dev)
 ref.load_state_dict(model.state_dict())
 b = timeit(ref, "vendor-library convolutions")
