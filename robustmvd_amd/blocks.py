@@ -299,6 +299,8 @@ class CostRegNet(nn.Module):
         pk["conv0_f16"] = ops.pack_conv3d_weights_f16(self.conv0.conv.weight.detach())
         if self.conv0_split:  # split-operand kernels: conv0 on the plane-marching one, conv1 .. conv4 and conv6 on the implicit GEMM
             pk["conv0_split"] = ops.pack_conv3d_weights_split(self.conv0.conv.weight.detach())
+            sc0, sh0 = pk["conv0"][3], pk["conv0"][4]
+            pk["conv0_bound"] = ((self.conv0.conv.weight.detach().abs().sum(dim=(1, 2, 3, 4)) * sc0.abs()).contiguous(), sh0.abs().contiguous())
             for name, _, _, stride in self.LAYERS:
                 if name in ("conv1", "conv2", "conv3", "conv4", "conv6"):
                     pk[name + "_igemm"] = ops.pack_conv3d_weights_igemm(getattr(self, name).conv.weight.detach(),
@@ -325,8 +327,15 @@ class CostRegNet(nn.Module):
             a0 = None
         elif self.conv0_split:
             _, _, _, scale0, shift0, _ = pk["conv0"]
-            # (max |conv0| by a pass of its own: as a by-product of the kernel's store epilogue it cost twice that, 58 us)
-            conv0, a0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True, x_absmax=x_absmax), None
+            # The range of conv0's output for conv1: an upper BOUND from max |x| and the layer's weights instead of a measurement
+            # (|y_c| <= |scale_c| sum|w_c| max|x| + |shift_c|).  Measuring costs a pass over 453 MB (85 us) or, as a by-product of the
+            # kernel's store epilogue, 58 us; the bound is 10-50x loose, which moves the absolute error floor of conv1's activations
+            # from 2^-39 to about 2^-33 of the true maximum: still below fp32's own rounding of the sums they enter.
+            if x_absmax is None:
+                x_absmax = ops.absmax(x)
+            conv0 = ops.conv3d_bn_relu_split(x, pk["conv0_split"], scale0, shift0, relu=True, x_absmax=x_absmax)
+            gain0, off0 = pk["conv0_bound"]
+            a0 = (gain0 * x_absmax + off0).amax().reshape(1)
         else:
             conv0 = layer("conv0", x)
         if self.conv0_split:
