@@ -297,12 +297,12 @@ class CostRegNet(nn.Module):
         pk["prob"] = (w, 8, 1, torch.ones(1, device=w.device), self.prob.bias.detach().contiguous(), L.CONV3D_STRIDE1)
         # fp16-feature variant (BASELINE configs[3]): conv0's weights rounded to fp16 in fp16-MFMA fragment order
         pk["conv0_f16"] = ops.pack_conv3d_weights_f16(self.conv0.conv.weight.detach())
-        if self.conv0_split:  # split-operand kernels: conv0 on the plane-marching one, conv1 .. conv4 and conv6 on the implicit GEMM
+        if self.conv0_split:  # split-operand kernels: conv0 on the plane-marching one, conv1 .. conv6 on the implicit GEMM
             pk["conv0_split"] = ops.pack_conv3d_weights_split(self.conv0.conv.weight.detach())
             sc0, sh0 = pk["conv0"][3], pk["conv0"][4]
             pk["conv0_bound"] = ((self.conv0.conv.weight.detach().abs().sum(dim=(1, 2, 3, 4)) * sc0.abs()).contiguous(), sh0.abs().contiguous())
             for name, _, _, stride in self.LAYERS:
-                if name in ("conv1", "conv2", "conv3", "conv4", "conv6"):
+                if name != "conv0":
                     pk[name + "_igemm"] = ops.pack_conv3d_weights_igemm(getattr(self, name).conv.weight.detach(),
                                                                         L.CONV3D_STRIDE1 if stride == 1 else L.CONV3D_STRIDE2)
         self._packed, self._packed_key = pk, key
@@ -339,10 +339,9 @@ class CostRegNet(nn.Module):
         else:
             conv0 = layer("conv0", x)
         if self.conv0_split:
-            # conv1 .. conv6 on the split-operand kernels, each scaled by max |x| of its input, which the layer before leaves behind
-            # as a by-product of its store epilogue: conv1, conv3 (stride 2), conv2, conv4, conv6 (stride 1) on the implicit-GEMM
-            # kernel of the 2-D engine (depth taps as chunks), conv5 and the transposed layers on the fp32 matrix instruction
-            # (measured faster there: tools/bench_k4_igemm.py)
+            # conv1 .. conv6 on the implicit-GEMM split kernel of the 2-D engine (depth taps as chunks), each scaled by max |x| of its
+            # input, which the layer before leaves behind as a by-product of its store epilogue; the transposed layers and `prob`
+            # on the fp32 matrix instruction / vector ALU (measured faster there: tools/bench_k4_igemm.py)
             def ig(name, t, a, want_absmax=True):
                 _, cin, cout, sc, sh, mode = pk[name]
                 return ops.conv3d_bn_relu_igemm(t, a, pk[name + "_igemm"], cin, cout, sc, sh, mode, relu=True, return_absmax=want_absmax)
@@ -352,9 +351,8 @@ class CostRegNet(nn.Module):
             t, a = ig("conv1", conv0, a0)
             conv2, a = ig("conv2", t, a)
             t, a = ig("conv3", conv2, a)
-            conv4, a = ig("conv4", t, a, want_absmax=False), None
-            w5, cin5, cout5, sc5, sh5, mode5 = pk["conv5"]
-            t, a = ops.conv3d_bn_relu(conv4, w5, cin5, cout5, sc5, sh5, mode5, relu=True, return_absmax=True)
+            conv4, a = ig("conv4", t, a)
+            t, a = ig("conv5", conv4, a)
             y = ig("conv6", t, a, want_absmax=False)
         else:
             conv2 = layer("conv2", layer("conv1", conv0))

@@ -164,22 +164,42 @@ __global__ void c2_pack_kernel(const float* __restrict__ w, const float* __restr
 }
 
 // epilogue of 4 consecutive output channels cb .. cb + 3 of output pixel (oy, ox) of image bi (main kernel and split-K reduce)
-__device__ __forceinline__ void c2_finish(const C2Params& p, int bi, int oy, int ox, int cls, int cb, c2f4 a, float xsc_inv, float& amax) {
-    const int od = bi % p.Do, b = bi / p.Do;
+// the per-channel constants of output channels cb .. cb + 3 (loaded once per channel group, not once per pixel)
+struct C2Chan {
+    float mul[4], sc[4], bi[4];  // 2^(e + k_c); batch-norm scale (1 when there is none); bias / shift
+};
+__device__ __forceinline__ C2Chan c2_chan(const C2Params& p, int cb, float xsc_inv) {
+    C2Chan k;
+    const int c = p.sub3d ? cb % p.Cr : cb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool in = cb + r < p.Cout;
+        k.mul[r] = in ? p.eun[cb + r] * xsc_inv : 0.f;
+        k.sc[r] = (in && p.scale) ? p.scale[c + r] : 1.f;
+        k.bi[r] = (in && p.bias) ? p.bias[c + r] : 0.f;
+    }
+    return k;
+}
+// offset (floats) of output channel cb of output pixel (oy, ox) of image (b, od); consecutive oy are c2_row_step(p) apart
+__device__ __forceinline__ size_t c2_out_offset(const C2Params& p, int b, int od, int oy, int ox, int cls, int cb) {
     int c = cb, zo = od, yo = oy * p.oy_mul + (cls >> 1), xo = ox * p.ox_mul + (cls & 1);
     if (p.sub3d) {
         const int k3 = cb / p.Cr;
         c = cb - k3 * p.Cr;
         zo = 2 * od + (k3 >> 2); yo = 2 * oy + ((k3 >> 1) & 1); xo = 2 * ox + (k3 & 1);
     }
-    const size_t o = ((size_t)b * p.Dy + zo) * p.ys_img + (size_t)yo * p.ys_row + (size_t)xo * p.ys + (size_t)c * p.ycs;
+    return ((size_t)b * p.Dy + zo) * p.ys_img + (size_t)yo * p.ys_row + (size_t)xo * p.ys + (size_t)c * p.ycs;
+}
+__device__ __forceinline__ size_t c2_row_step(const C2Params& p) { return (size_t)(p.sub3d ? 2 : p.oy_mul) * p.ys_row; }
+// epilogue of 4 consecutive output channels cb .. cb + 3 at output offset o (main kernel and split-K reduce)
+__device__ __forceinline__ void c2_finish(const C2Params& p, size_t o, int cb, c2f4 a, const C2Chan& k, float& amax) {
     float r4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float v = 0.f;
         if (cb + r < p.Cout) {
-            const float conv = a[r] * (p.eun[cb + r] * xsc_inv);  // exact: powers of two
-            v = p.scale ? fmaf(conv, p.scale[c + r], p.bias[c + r]) : conv + (p.bias ? p.bias[c + r] : 0.f);
+            const float conv = a[r] * k.mul[r];  // exact: a power of two
+            v = p.scale ? fmaf(conv, k.sc[r], k.bi[r]) : conv + k.bi[r];
             if (p.act == 1) v = v > 0.f ? v : v * p.slope;
             else if (p.act == 2) v = fmaxf(v, 0.f);
             if (p.skip) v += p.skip[o + r * p.ycs];
@@ -410,12 +430,13 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
             continue;
         }
         if (cb >= p.Cout || ((C2_KO & 16) && p.B > 1000)) continue;
-        if (ox < p.Wo)
+        const C2Chan kc = c2_chan(p, cb, xsc_inv);
+        if (ox < p.Wo) {
+            const size_t o0 = c2_out_offset(p, bb, od, oy0 + wm * MTW, ox, cls, cb), ostep = c2_row_step(p);
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int oy = oy0 + wm * MTW + m;
-                if (oy < p.Ho) c2_finish(p, b, oy, ox, cls, cb, acc[m][t], xsc_inv, amax);
-            }
+            for (int m = 0; m < MTW; ++m)
+                if (oy0 + wm * MTW + m < p.Ho) c2_finish(p, o0 + m * ostep, cb, acc[m][t], kc, amax);
+        }
     }
     if (p.yamax && !p.part) {
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
@@ -466,7 +487,7 @@ __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
             s += v1;
         }
         const int ox = (int)(pl % p.Wo), oy = (int)((pl / p.Wo) % p.Ho), b = (int)(pl / ((long long)p.Wo * p.Ho));
-        c2_finish(p, b, oy, ox, cls, cb, s, xsc_inv, amax);
+        c2_finish(p, c2_out_offset(p, b / p.Do, b % p.Do, oy, ox, cls, cb), cb, s, c2_chan(p, cb, xsc_inv), amax);
     }
     if (p.yamax) {
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
