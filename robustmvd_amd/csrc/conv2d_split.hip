@@ -454,8 +454,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
 // agent-scope release every workgroup then needs before its ticket writes back its XCD's whole L2: the split layers ran 2-5x slower.)
 __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
     __shared__ float wmax[4];
-    const long long npix = (long long)p.B * p.Ho * p.Wo;
+    // 32-bit index arithmetic (the launcher checks B Ho Wo Cout / 4 < 2^31): with 64-bit divisions in the decode this pass took
+    // 2-3x the time of its reads.  blockIdx.y = parity class of a transposed layer.
+    const int npix = p.B * p.Ho * p.Wo;
     const int c4n = (p.Cout + 3) / 4;
+    const int cls = blockIdx.y;
     float xsc_inv;
     {
         const unsigned mb = __float_as_uint(*p.xamax);
@@ -464,11 +467,10 @@ __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
         xsc_inv = __uint_as_float((unsigned)(127 + e) << 23);
     }
     float amax = 0.f;
-    // grid-stride: at most a few hundred workgroups, each ends with ONE atomic (they serialise on the address)
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix * c4n * p.ncls; i += (long long)gridDim.x * 256) {
-        const int cls = (int)(i / (npix * c4n));
-        const long long pl = (i / c4n) % npix;
-        const int cb = (int)(i % c4n) * 4;
+    // grid-stride: a workgroup ends with at most one atomic
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix * c4n; i += gridDim.x * 256) {
+        const int pl = i / c4n;
+        const int cb = (i - pl * c4n) * 4;
         // ksplit is a power of two >= 2: eight loads in flight, added in the fixed order ks = 0, 1, ...
         const float* pp = p.part + ((size_t)cls * p.ksplit * npix + pl) * p.ncp + cb;
         const size_t kstr = (size_t)npix * p.ncp;
@@ -486,8 +488,9 @@ __global__ void __launch_bounds__(256) c2_reduce_kernel(C2Params p) {
             s += v0;
             s += v1;
         }
-        const int ox = (int)(pl % p.Wo), oy = (int)((pl / p.Wo) % p.Ho), b = (int)(pl / ((long long)p.Wo * p.Ho));
-        c2_finish(p, c2_out_offset(p, b / p.Do, b % p.Do, oy, ox, cls, cb), cb, s, c2_chan(p, cb, xsc_inv), amax);
+        const int row = pl / p.Wo, ox = pl - row * p.Wo, b = row / p.Ho, oy = row - b * p.Ho;
+        const int bb = p.Do == 1 ? b : b / p.Do, od = b - bb * p.Do;
+        c2_finish(p, c2_out_offset(p, bb, od, oy, ox, cls, cb), cb, s, c2_chan(p, cb, xsc_inv), amax);
     }
     if (p.yamax) {
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
@@ -793,8 +796,9 @@ int mvd_conv2d_split_f32(const float* x, const float* x_absmax, const void* pack
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv2d_split: %lld workgroups exceed the grid limit", nblk);
     int rc = mvd::c2_dispatch(s, p, bn, nblk, st);
     if (rc != MVD_OK || ksplit == 1) return rc;
-    const long long n = (long long)p.ncls * B * p.Ho * p.Wo * ((Cout + 3) / 4);
-    hipLaunchKernelGGL(mvd::c2_reduce_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 512)), dim3(256), 0, st, p);
+    const long long n = (long long)B * p.Ho * p.Wo * ((Cout + 3) / 4);
+    MVD_REQUIRE(n < 0x7fffffffLL, "conv2d_split: split reduction over %lld outputs", n);
+    hipLaunchKernelGGL(mvd::c2_reduce_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)p.ncls), dim3(256), 0, st, p);
     return mvd::launch_status("conv2d_split: reduce");
 }
 
@@ -921,7 +925,8 @@ int mvd_conv3d_bn_relu_igemm_f32(const float* x, const float* x_absmax, const vo
     int rc = mvd::c2_dispatch(s, p, q.bn, nblk, st);
     if (rc != MVD_OK || ksplit == 1) return rc;
     const long long n = (long long)p.B * p.Ho * p.Wo * ((p.Cout + 3) / 4);
-    hipLaunchKernelGGL(mvd::c2_reduce_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 512)), dim3(256), 0, st, p);
+    MVD_REQUIRE(n < 0x7fffffffLL, "conv3d_igemm: split reduction over %lld outputs", n);
+    hipLaunchKernelGGL(mvd::c2_reduce_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, p);
     return mvd::launch_status("conv3d_igemm: reduce");
 }
 }
