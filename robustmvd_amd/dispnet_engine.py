@@ -127,8 +127,10 @@ class DispnetEngine:
             # (conv2 reads before the decoder adds to the slots: every later writer only raises them, which stays a valid bound)
             ops.conv2d_split(cat4[..., :128], a_cat4, w["conv3"], out=c3k, out_absmax=a_c3k)
             ops.conv2d_split(c3k, a_c3k, w["conv_redir"], out=merged[..., :32], out_absmax=a_merged)
-        # (one launch over the concatenated source images: per-view launches of this layer measured 2.2x slower, tail effects)
-        src = torch.cat(list(images_source), 0) if V > 1 else images_source[0]
+        # (one launch over the batch of source images: per-view launches of this layer measured 2.2x slower, tail effects; the batch is a
+        # view, not a copy, when the images are slices of one buffer, as the input adapter leaves them)
+        from .models import _as_batch
+        src = _as_batch(list(images_source))
         s1, a1 = layer("conv1", src, ops.absmax(src))
         s2, a2 = layer("conv2", s1, a1)
         del s1

@@ -51,6 +51,30 @@ def _upscale_to_multiple(images, intrinsics, m, device):
     return images, intrinsics, ht, wd
 
 
+def _stack_views(images, fn):
+    """fn(image) for every view, written into ONE buffer when the views have equal shapes, and returned as its slices: what the
+    forwards batch over (`torch.cat` of the views, robust_mvd.py / mvsnet.py) is then a zero-copy view (`_as_batch`).
+    fn's result is converted to float32 by the copy into the buffer (one rounding, as `.float()` would)."""
+    if len(images) < 2 or any(im.shape != images[0].shape for im in images):
+        return [fn(im).float() for im in images]
+    buf = torch.empty((len(images),) + tuple(images[0].shape), dtype=torch.float32, device=images[0].device)
+    for i, im in enumerate(images):
+        buf[i].copy_(fn(im))
+    return [buf[i] for i in range(len(images))]
+
+
+def _as_batch(views):
+    """torch.cat(views, 0) — without the copy when the views are consecutive slices of one buffer (`_stack_views`)."""
+    v0 = views[0]
+    if len(views) == 1:
+        return v0
+    step = v0.numel() * v0.element_size()
+    if all(v.shape == v0.shape and v.dtype == v0.dtype and v.is_contiguous() and v.untyped_storage().data_ptr() == v0.untyped_storage().data_ptr()
+           and v.data_ptr() == v0.data_ptr() + i * step for i, v in enumerate(views)):
+        return torch.as_strided(v0, (len(views) * v0.shape[0],) + tuple(v0.shape[1:]), v0.stride())
+    return torch.cat(list(views), 0)
+
+
 class RobustMVD(nn.Module):
     def __init__(self, half_dispnet=False, engine_dispnet=True):
         """engine_dispnet (default on): at inference on the GPU in fp32 the whole 2-D CNN around the sweep runs on the engine's
@@ -115,7 +139,7 @@ class RobustMVD(nn.Module):
             dec = self._engine.forward(image_key, images_source, intrinsics_key, intrinsics_source, source_to_key)
             return self._outputs(dec)
         if same:  # one encoder pass over key + all sources
-            feats = self.encoder.conv3(self.encoder.conv2(self.encoder.conv1(torch.cat(images_source, 0))))
+            feats = self.encoder.conv3(self.encoder.conv2(self.encoder.conv1(_as_batch(images_source))))
             enc_sources = list(torch.split(feats, n, 0))
         else:
             enc_sources = [self.encoder(im)[1] for im in images_source]
@@ -150,7 +174,7 @@ class RobustMVD(nn.Module):
         # im / 255 - 0.4 (robust_mvd.py:113-116) on the device: the raw images are uploaded, the arithmetic is the
         # reference's float32 operations one by one (true division by a tensor, not torch's scalar-reciprocal shortcut)
         c255 = torch.full((1,), 255.0, dtype=torch.float32, device=device)
-        images = [im / c255 - 0.4 for im in images]
+        images = _stack_views(images, lambda im: im / c255 - 0.4)
         poses = [p.float() for p in poses]
         intrinsics = [k.float() for k in intrinsics]
         return {"images": images, "keyview_idx": keyview_idx, "poses": poses, "intrinsics": intrinsics}
@@ -240,7 +264,7 @@ class MVSNet(nn.Module):
         projs = [select_by_index(proj, kidx)] + exclude_index(proj, kidx)
 
         # K6 x 8: ((V+1)*B, h+3, w+3, 32), the last layer writing straight into K3's zero-bordered staging layout
-        feats = self.feature.forward_layout(torch.cat(views, 0), L.LAYOUT_NHWC_BORDER)
+        feats = self.feature.forward_layout(_as_batch(views), L.LAYOUT_NHWC_BORDER)
         if self.half_features:
             feats = ops.to_f16(feats)  # one rounding to fp16 (zero border stays zero)
         feats = list(torch.split(feats, n, 0))
@@ -272,11 +296,11 @@ class MVSNet(nn.Module):
         mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float64, device=device).view(-1, 1, 1)
         std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float64, device=device).view(-1, 1, 1)
         c255 = torch.full((1,), 255.0, dtype=torch.float32, device=device)
-        images = [(((im.float() / c255).double() - mean) / std).float() for im in images]
+        images = _stack_views(images, lambda im: ((im.float() / c255).double() - mean) / std)
         # stay on the host: keyview_idx only orders the views, depth_range only seeds torch.linspace, and the 4x4
         # calibration products are cheaper there than as a dozen tiny launches (forward accepts either placement)
         keyview_idx, depth_range, intrinsics, poses = to_torch((keyview_idx, depth_range, intrinsics, poses))
-        return {"images": [im.float() for im in images], "poses": poses, "intrinsics": intrinsics,
+        return {"images": images, "poses": poses, "intrinsics": intrinsics,
                 "keyview_idx": keyview_idx, "depth_range": depth_range, "masks": masks}
 
     def output_adapter(self, model_output):
