@@ -255,8 +255,8 @@ int mvd_conv3d_bn_relu_absmax_f32_split(const float* x, const float* x_absmax, c
  * 2x2x2 convolution with 8 Cout output channels = (parity class, channel)).  x (B,Di,Hi,Wi,Cin) channel-last fp32, Cin a multiple of 8
  * (16 for the transposed form), Cout a multiple of 4; mode MVD_CONV3D_STRIDE1 / _STRIDE2 / MVD_DECONV3D_STRIDE2 with the output
  * sizes of mvd_conv3d_bn_relu_f32; weights in Conv3d / ConvTranspose3d layout.  y = relu?(conv * scale + shift) (+ skip, laid out
- * like y, may be NULL).  x_absmax as for mvd_conv3d_bn_relu_f32_split; y_absmax NULL or a device float that receives max |y|
- * (set by this call).  workspace NULL or mvd_conv3d_igemm_workspace_bytes bytes (few-voxel layers split the reduction). */
+ * like y, may be NULL).  x_absmax as for mvd_conv3d_bn_relu_f32_split; y_absmax NULL or a device float that is RAISED to max |y|
+ * (atomic maximum: the caller zeroes it, as for mvd_conv2d_split_f32).  workspace NULL or mvd_conv3d_igemm_workspace_bytes bytes (few-voxel layers split the reduction). */
 size_t mvd_conv3d_igemm_packed_weight_bytes(int Cin, int Cout, int mode);
 int mvd_pack_conv3d_weights_igemm(const float* w, int Cin, int Cout, int mode, void* packed, mvd_stream_t stream);
 size_t mvd_conv3d_igemm_workspace_bytes(int B, int Di, int Hi, int Wi, int Cin, int Cout, int mode);

@@ -342,9 +342,17 @@ class CostRegNet(nn.Module):
             # conv1 .. conv6 on the implicit-GEMM split kernel of the 2-D engine (depth taps as chunks), each scaled by max |x| of its
             # input, which the layer before leaves behind as a by-product of its store epilogue; the transposed layers and `prob`
             # on the fp32 matrix instruction / vector ALU (measured faster there: tools/bench_k4_igemm.py)
+            slots = torch.zeros(8, dtype=torch.float32, device=x.device)  # the layers' max-|y| slots: one fill for all
+            nslot = [0]
+
             def ig(name, t, a, want_absmax=True):
                 _, cin, cout, sc, sh, mode = pk[name]
-                return ops.conv3d_bn_relu_igemm(t, a, pk[name + "_igemm"], cin, cout, sc, sh, mode, relu=True, return_absmax=want_absmax)
+                out_a = None
+                if want_absmax:
+                    out_a = slots[nslot[0]:nslot[0] + 1]
+                    nslot[0] += 1
+                return ops.conv3d_bn_relu_igemm(t, a, pk[name + "_igemm"], cin, cout, sc, sh, mode, relu=True, return_absmax=want_absmax,
+                                                out_absmax=out_a)
 
             if a0 is None:
                 a0 = ops.absmax(conv0)

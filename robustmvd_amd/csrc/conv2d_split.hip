@@ -921,7 +921,6 @@ int mvd_conv3d_bn_relu_igemm_f32(const float* x, const float* x_absmax, const vo
     p.part = ksplit > 1 ? static_cast<float*>(workspace) : nullptr;
     const long long nblk = q.tiles * ksplit;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "conv3d_igemm: %lld workgroups exceed the grid limit", nblk);
-    if (y_absmax && hipMemsetAsync(y_absmax, 0, sizeof(float), st) != hipSuccess) return mvd::launch_status("conv3d_igemm: memset");
     int rc = mvd::c2_dispatch(s, p, q.bn, nblk, st);
     if (rc != MVD_OK || ksplit == 1) return rc;
     const long long n = (long long)p.B * p.Ho * p.Wo * ((p.Cout + 3) / 4);

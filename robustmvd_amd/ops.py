@@ -462,10 +462,11 @@ def pack_conv3d_weights_igemm(weight, mode):
 
 
 @inference_only
-def conv3d_bn_relu_igemm(x, x_absmax, packed, Cin, Cout, scale, shift, mode, relu=True, skip=None, return_absmax=False):
+def conv3d_bn_relu_igemm(x, x_absmax, packed, Cin, Cout, scale, shift, mode, relu=True, skip=None, return_absmax=False, out_absmax=None):
     """K4's stride-2 / transposed / wide stride-1 layers on the split-operand implicit-GEMM kernel (mvd_conv3d_bn_relu_igemm_f32).
     x (B,D,h,w,Cin) channel-last fp32, x_absmax one-element device tensor with max |x| -> (B,Do,ho,wo,Cout); skip (like the output)
-    is added after the activation.  return_absmax: also max |y|."""
+    is added after the activation.  return_absmax: also max |y| (out_absmax: a zeroed one-element device tensor to raise instead of a
+    fresh one: several layers' slots can come from one zeroed buffer)."""
     lib = L.load()
     x = L.as_f32(x, "x")
     if x.dim() != 5 or x.shape[-1] != Cin:
@@ -490,7 +491,9 @@ def conv3d_bn_relu_igemm(x, x_absmax, packed, Cin, Cout, scale, shift, mode, rel
         skip = L.as_f32(skip, "skip", oshape, dev)
     xam = L.as_f32(x_absmax, "x_absmax", (1,), dev)
     y = torch.empty(oshape, dtype=torch.float32, device=dev)
-    yam = torch.empty(1, dtype=torch.float32, device=dev) if return_absmax else None
+    yam = None
+    if return_absmax:
+        yam = torch.zeros(1, dtype=torch.float32, device=dev) if out_absmax is None else L.as_f32(out_absmax, "out_absmax", (1,), dev)
     wsb = lib.mvd_conv3d_igemm_workspace_bytes(B, Di, hi, wi, Cin, Cout, mode)
     wsp = _workspace(wsb, dev) if wsb else None
     with torch.cuda.device(dev):
