@@ -503,6 +503,32 @@ def main(argv=None):
                                       "algorithmic_flops_per_launch": k1_flops, "algorithmic_bytes_per_launch": k1_bytes,
                                       "algorithmic_gbs": k1_bytes / (k1_ms * 1e-3) / 1e9, "avg_launch_ms": k1_ms,
                                       "launches_timed": args.steps, "pmc": k1_pmc}}
+        # second roofline block of Path A: the longest convolution of its 2-D CNN (encoder conv2: 5x5, stride 2, 64 -> 128, the V source
+        # views as one batch) on the split-operand implicit-GEMM kernel, against the dense fp16 matrix peak; timed standalone
+        from robustmvd_amd import ops as ops_a
+        wts2 = ma._engine._prepare()["conv2"]
+        x2 = torch.rand(V, H // 2, W // 2, 64, device=dev)
+        am2, ya2 = ops_a.absmax(x2), torch.zeros(1, device=dev)
+        for _ in range(3):
+            y2 = ops_a.conv2d_split(x2, am2, wts2, out_absmax=ya2)
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        for _ in range(10):
+            y2 = ops_a.conv2d_split(x2, am2, wts2, out_absmax=ya2)
+        f1.record()
+        torch.cuda.synchronize(dev)
+        ms2 = f0.elapsed_time(f1) / 10
+        px2 = V * (H // 4) * (W // 4)
+        flops2 = 2.0 * px2 * 128 * 64 * 25                               # the layer's arithmetic
+        issued2 = 3 * 2.0 * px2 * 128 * 8 * 28                           # 3 products, 28 K units of 8 channels for 25 taps x 8 chunks
+        out["path_a"]["roofline_mfma"] = {
+            "bound": "mfma", "kernel": "conv2d_split_kernel<5,5,2> (encoder conv2, 64->128, 5x5 stride 2, %d views)" % V,
+            "achieved": issued2 / ms2 / 1e9, "peak": 2500.0, "unit": "TFLOP/s", "frac": issued2 / ms2 / 1e9 / 2500.0,
+            "issued_flops_per_launch": issued2, "algorithmic_flops_per_launch": flops2, "fp32_equivalent_tflops": flops2 / ms2 / 1e9,
+            "avg_launch_ms": ms2, "launches_timed": 10,
+            "note": "dense fp16 MFMA peak; fp32 operands as two fp16 terms, three products per multiply; matrix pipe 38 % busy by "
+                    "counters (profiles/r03_conv2d_5x5_pmc.txt), the rest is patch staging and waits (DESIGN.md 4)"}
+        del x2, y2
         # two frames in flight (FramePipeline: two HIP streams): the decoder's small layers of one frame overlap the encoder of the next
         import robustmvd_amd as R2
         pipe_a = R2.FramePipeline(ma, depth=2)
