@@ -520,7 +520,7 @@ def main(argv=None):
         ms2 = f0.elapsed_time(f1) / 10
         px2 = V * (H // 4) * (W // 4)
         flops2 = 2.0 * px2 * 128 * 64 * 25                               # the layer's arithmetic
-        issued2 = 3 * 2.0 * px2 * 128 * 8 * 28                           # 3 products, 28 K units of 8 channels for 25 taps x 8 chunks
+        issued2 = 3 * 2.0 * px2 * 128 * (64 // 8) * 28 * 8               # 3 products; per 8-channel chunk 7 K steps = 28 units of 8 (25 taps)
         out["path_a"]["roofline_mfma"] = {
             "bound": "mfma", "kernel": "conv2d_split_kernel<5,5,2> (encoder conv2, 64->128, 5x5 stride 2, %d views)" % V,
             "achieved": issued2 / ms2 / 1e9, "peak": 2500.0, "unit": "TFLOP/s", "frac": issued2 / ms2 / 1e9 / 2500.0,
