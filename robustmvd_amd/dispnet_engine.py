@@ -69,7 +69,8 @@ class DispnetEngine:
         key = (n, H, W, V, str(dev), torch.cuda.current_stream(dev).cuda_stream)
         b = self._bufs.get(key)
         if b is None:
-            if len(self._bufs) >= 4:
+            if len(self._bufs) >= 8:  # (shape, stream) combinations come and go: drop them all, but only once nothing in flight uses them
+                torch.cuda.synchronize(dev)
                 self._bufs.clear()
             z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
             h8, w8 = H // 8, W // 8
