@@ -45,17 +45,22 @@ constexpr int C2_TH = 16, C2_TW = 16;  // output pixels per workgroup tile
 template <int KH, int KW, int S, int U8, bool IMG = false>
 struct C2Geom {
     static constexpr int CC = 8 * U8;                          // input channels per staged chunk
-    static constexpr int PB = CC * 2 + (U8 % 2 == 0 ? 16 : 0); // LDS bytes per pixel and term: PB / 16 odd = conflict-free rows
+    static constexpr int PB = 16;                              // LDS bytes per pixel, term and 8-channel group
     static constexpr int PH = (C2_TH - 1) * S + KH, PW = (C2_TW - 1) * S + KW;  // staged patch
     static constexpr int PWS = (PW + S - 1) / S;               // columns per parity plane
     static constexpr int ROWB = S * S * PWS * PB;              // LDS bytes between the patch rows of consecutive OUTPUT rows
-    static constexpr int PLANE = PH * S * PWS * PB;            // one term of the patch
+    // The 8-channel groups of a chunk are PLANES C8S bytes apart, C8S a multiple of the 256-byte bank row: `ds_read_b128` serves the
+    // lanes in four NON-contiguous groups of 16 ({0-3, 12-15, 20-27}, ...), i.e. 8 pixels of one K group of the fragment and the
+    // other 8 pixels of the next; with the K groups (= channel groups, when a chunk has 4) a whole number of bank rows apart those
+    // 16 lanes read 16 different 16-byte slots.  (Pixel-interleaved groups at an odd pitch of 80 bytes kept ONE K group conflict-free
+    // but not the hardware's groups: half of the LDS cycles were bank conflicts, profiles/r03_conv2d_fusion3x3_pmc.txt.)
+    static constexpr int C8S = (PH * S * PWS * PB + 255) / 256 * 256;
+    static constexpr int PLANE = U8 * C8S;                     // one term of the patch
     static constexpr int UNITS = KH * KW * U8;                 // (tap, 8-channel group) units per chunk
     static constexpr int STEPS = (UNITS + 3) / 4;              // MFMA K steps (32 = 4 units) per chunk
     static constexpr int ITEMS = PH * PW * U8;                 // staging items (pixel, 8-channel group)
     static constexpr int NIT = (ITEMS + 255) / 256;
     static_assert(2 * PLANE <= 80 * 1024, "patch exceeds half the LDS (two workgroups per CU)");
-    static_assert((PB / 16) % 2 == 1, "pixel pitch must be an odd number of 16-byte slots");
 };
 // The first layer on a planar 3-channel image (7 x 7, stride 2): a pixel is 4 halves (r, g, b, 0) = 8 bytes, rows are stored as
 // they are (no parity planes), so the 16 bytes a lane reads are the TWO x-adjacent pixels of taps kx = 2g, 2g + 1 and a K step is
@@ -279,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
             loff[k] = live ? pix * PB : -1;
         } else {  // inside its input image; the image (plane) is the chunk's
             goff[k] = inside ? ((long long)iy * p.Wi + ix) * p.xs + c8 * 8 : -1;
-            loff[k] = live ? ((py * S + pxx % S) * G::PWS + pxx / S) * PB + c8 * 16 : -1;
+            loff[k] = live ? ((py * S + pxx % S) * G::PWS + pxx / S) * PB + c8 * G::C8S : -1;
         }
     }
     // activation fragment address of this lane per K step (row 0 of the wave's rows)
@@ -292,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
             int unit = 4 * s + g;
             if (unit >= G::UNITS) unit = 0;  // meets zero weights
             const int tap = unit / U8, c8 = unit % U8, ky = tap / KW, kx = tap % KW;
-            tapoff[s] = ((ky * S + kx % S) * G::PWS + kx / S + px16) * PB + c8 * 16 + wm * MTW * G::ROWB;
+            tapoff[s] = ((ky * S + kx % S) * G::PWS + kx / S + px16) * PB + c8 * G::C8S + wm * MTW * G::ROWB;
         }
     }
 
