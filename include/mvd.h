@@ -318,6 +318,11 @@ int mvd_pack_conv2d_weights_f32(const float* w, int Cin, int Cout, int ksize, fl
 int mvd_conv2d_bn_relu_f32(const float* x, int in_layout, const float* packed_w, const float* scale, const float* shift,
                            float* y, int out_layout, int B, int hi, int wi, int Cin, int Cout, int ksize, int stride,
                            int relu, mvd_stream_t stream);
+/* The same, and *y_absmax (device, one float; the caller zeroes it) RAISED to max |y| over the finite outputs: what a split-operand
+ * layer behind this one (mvd_conv2d_split_f32) scales its activations by.  A by-product of the store epilogue. */
+int mvd_conv2d_bn_relu_absmax_f32(const float* x, int in_layout, const float* packed_w, const float* scale, const float* shift,
+                                  float* y, float* y_absmax, int out_layout, int B, int hi, int wi, int Cin, int Cout, int ksize,
+                                  int stride, int relu, mvd_stream_t stream);
 
 /* K5 — replaces F.softmax + depth_regression + the 4-bin confidence of MVSNet.forward
  *   rmvd/models/mvsnet.py:139-160, rmvd/models/blocks/utils.py:271-274.

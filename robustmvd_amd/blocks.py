@@ -199,9 +199,14 @@ class FeatureNet(nn.Module):
     SPEC = [(3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1), (16, 16, 3, 1, 1),
             (16, 32, 5, 2, 2), (32, 32, 3, 1, 1)]
 
-    def __init__(self):
+    def __init__(self, split_layers=True):
+        """split_layers (default on): conv2 .. conv6 and `feature` run on the split-operand implicit-GEMM kernel of the 2-D engine
+        (ops.conv2d_split: fp32-grade, 1.2-1.5x the fp32 matrix instruction on these layers, tools/bench_featurenet_engine.py), the
+        BN scale folded into their weights; conv0 and conv1 (full resolution, 3 / 8 input channels: traffic-bound) stay on the
+        fp32-MFMA kernel, conv1 leaving max |y| behind for conv2.  False: all eight layers on the fp32 matrix instruction."""
         super().__init__()
         self.inplanes = 32
+        self.split_layers = bool(split_layers)
         for i, s in enumerate(self.SPEC):
             setattr(self, f"conv{i}", ConvBnReLU(*s))
         self.feature = nn.Conv2d(32, 32, 3, 1, 1)
@@ -222,6 +227,13 @@ class FeatureNet(nn.Module):
             pk.append((w, cin, cout, k, stride, *fold_bn(m.bn), True))
         w, _, _, _ = ops.pack_conv2d_weights(self.feature.weight.detach())
         pk.append((w, 32, 32, 3, 1, torch.ones(32, device=w.device), self.feature.bias.detach().contiguous(), False))
+        if self.split_layers:  # layers 2 .. 7 for the split-operand kernel: BN scale folded into the weights, shift as the bias
+            sp = []
+            for i in range(2, 8):
+                conv = getattr(self, f"conv{i}").conv if i < 7 else self.feature
+                _, _, _, _, stride, scale, shift, relu = pk[i]
+                sp.append((ops.pack_conv2d_weights_split(conv.weight.detach() * scale.view(-1, 1, 1, 1), shift, stride=stride), relu))
+            pk.append(sp)
         self._packed, self._packed_key = pk, key
         return pk
 
@@ -229,9 +241,28 @@ class FeatureNet(nn.Module):
     def forward_layout(self, x, out_layout):
         """x (N,3,H,W) normalised images -> features at H/4 x W/4 in `out_layout` (L.LAYOUT_*)."""
         pk = self._prepare()
-        for i, (w, cin, cout, k, stride, scale, shift, relu) in enumerate(pk):
-            x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu,
-                                   out_layout=out_layout if i == len(pk) - 1 else L.LAYOUT_NHWC)
+        if not self.split_layers:
+            for i, (w, cin, cout, k, stride, scale, shift, relu) in enumerate(pk):
+                x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu,
+                                       out_layout=out_layout if i == len(pk) - 1 else L.LAYOUT_NHWC)
+            return x
+        slots = torch.zeros(8, dtype=torch.float32, device=x.device)  # max-|y| slots of the layers, raised by their producers
+        for i in range(2):
+            w, cin, cout, k, stride, scale, shift, relu = pk[i]
+            x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu, out_absmax=slots[0:1] if i == 1 else None)
+        for j, (wts, relu) in enumerate(pk[8]):
+            last = j == len(pk[8]) - 1
+            if not last:
+                x = ops.conv2d_split(x, slots[j:j + 1], wts, act=2 if relu else 0, out_absmax=slots[j + 1:j + 2])
+            elif out_layout == L.LAYOUT_NCHW:
+                x = ops.conv2d_split(x, slots[j:j + 1], wts, act=0, planar_out=True)
+            elif out_layout == L.LAYOUT_NHWC_BORDER:  # K3's zero-bordered staging map: the layer writes the interior
+                B, h, w_, _ = x.shape
+                buf = torch.zeros((B, h + 3, w_ + 3, wts.cout), dtype=torch.float32, device=x.device)
+                ops.conv2d_split(x, slots[j:j + 1], wts, act=0, out=buf[:, 1:h + 1, 1:w_ + 1, :])
+                x = buf
+            else:
+                x = ops.conv2d_split(x, slots[j:j + 1], wts, act=0)
         return x
 
     def forward(self, x):

@@ -25,6 +25,7 @@ struct Conv2dParams {
     const float* scale;
     const float* shift;
     float* y;
+    float* absmax;  // optional (device, one float; the caller zeroes it): raised to max |y| over the finite outputs
     int B, hi, wi, ho, wo, Cout, relu;
     int tiles_w, tiles_h, tiles_per_xcd;
     long long osb, oorg;  // output batch stride and origin offset (floats)
@@ -226,6 +227,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(Conv2dParams p) {
             esh[n][k] = ch < p.Cout ? p.shift[ch] : 0.f;
         }
     float* __restrict__ yb = p.y + p.oorg + (size_t)b * p.osb;
+    float amax = 0.f;  // max |y| of this lane's outputs (p.absmax)
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int orow = r0 + wave * RPW + r;
@@ -244,6 +246,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(Conv2dParams p) {
                 for (int k = 0; k < 4; ++k) {
                     v[k] = fmaf(acc[r][m][n][k], esc[n][k], esh[n][k]);
                     if (p.relu) v[k] = fmaxf(v[k], 0.f);
+                    if (p.absmax && cb + k < p.Cout) amax = fmaxf(amax, finite_abs_or_zero(v[k]));
                 }
                 if (p.osch == 1) {
                     *reinterpret_cast<float4*>(yp + cb) = make_float4(v[0], v[1], v[2], v[3]);
@@ -253,6 +256,10 @@ __global__ void __launch_bounds__(256) conv2d_kernel(Conv2dParams p) {
                 }
             }
         }
+    }
+    if (p.absmax) {  // what a split-operand layer behind this one scales its activations by; a wave rarely has to raise the slot
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if ((threadIdx.x & 63) == 0) raise_absmax(p.absmax, amax);
     }
 }
 
@@ -320,9 +327,24 @@ int mvd_pack_conv2d_weights_f32(const float* w, int Cin, int Cout, int ksize, fl
     return mvd::launch_status("pack_conv2d_weights");
 }
 
+static int conv2d_entry(const float* x, int in_layout, const float* packed_w, const float* scale, const float* shift, float* y, float* y_absmax,
+                        int out_layout, int B, int hi, int wi, int Cin, int Cout, int ksize, int stride, int relu, mvd_stream_t stream);
+
 int mvd_conv2d_bn_relu_f32(const float* x, int in_layout, const float* packed_w, const float* scale, const float* shift,
                            float* y, int out_layout, int B, int hi, int wi, int Cin, int Cout, int ksize, int stride,
                            int relu, mvd_stream_t stream) {
+    return conv2d_entry(x, in_layout, packed_w, scale, shift, y, nullptr, out_layout, B, hi, wi, Cin, Cout, ksize, stride, relu, stream);
+}
+
+int mvd_conv2d_bn_relu_absmax_f32(const float* x, int in_layout, const float* packed_w, const float* scale, const float* shift,
+                                  float* y, float* y_absmax, int out_layout, int B, int hi, int wi, int Cin, int Cout, int ksize,
+                                  int stride, int relu, mvd_stream_t stream) {
+    MVD_REQUIRE(y_absmax, "conv2d_absmax: NULL argument");
+    return conv2d_entry(x, in_layout, packed_w, scale, shift, y, y_absmax, out_layout, B, hi, wi, Cin, Cout, ksize, stride, relu, stream);
+}
+
+static int conv2d_entry(const float* x, int in_layout, const float* packed_w, const float* scale, const float* shift, float* y, float* y_absmax,
+                        int out_layout, int B, int hi, int wi, int Cin, int Cout, int ksize, int stride, int relu, mvd_stream_t stream) {
     MVD_REQUIRE(x && packed_w && scale && shift && y, "conv2d: NULL argument");
     MVD_REQUIRE(B > 0 && hi > 0 && wi > 0, "conv2d: non-positive dimension");
     MVD_REQUIRE((long long)(hi + 3) * (wi + 3) * 32 < 0x7fffffffLL, "conv2d: one %dx%d image exceeds the 32-bit index range", hi, wi);
@@ -330,7 +352,7 @@ int mvd_conv2d_bn_relu_f32(const float* x, int in_layout, const float* packed_w,
     MVD_REQUIRE((Cin == 3) == (in_layout == MVD_LAYOUT_NCHW), "conv2d: a 3-channel input must be NCHW and a wider one NHWC");
     MVD_REQUIRE(in_layout == MVD_LAYOUT_NCHW || in_layout == MVD_LAYOUT_NHWC, "conv2d: in_layout=%d unknown", in_layout);
     mvd::Conv2dParams p{};
-    p.x = x; p.wpk = packed_w; p.scale = scale; p.shift = shift; p.y = y;
+    p.x = x; p.wpk = packed_w; p.scale = scale; p.shift = shift; p.y = y; p.absmax = y_absmax;
     p.B = B; p.hi = hi; p.wi = wi; p.Cout = Cout; p.relu = relu;
     p.ho = (hi - 1) / stride + 1;  // padding k/2: floor((h + 2*(k/2) - k) / s) + 1
     p.wo = (wi - 1) / stride + 1;

@@ -199,7 +199,7 @@ class MVSNet(nn.Module):
         if sample_in_inv_depth_space:
             raise NotImplementedError("sample_in_inv_depth_space=True is a dead branch in the reference "
                                       "(tensor[::-1] raises, mvsnet.py:50,56-63)")
-        self.feature = FeatureNet()
+        self.feature = FeatureNet(split_layers=conv0_split)  # same switch: False = every layer on the fp32 matrix instruction
         self.cost_regularization = CostRegNet(conv0_split=conv0_split)  # split-operand first layer, see CostRegNet
         self.exact_grid = bool(exact_grid)  # K3's sampling positions by the reference's own rounding chain (blocks/utils.py:234-266)
         self.num_sampling_steps = num_sampling_steps

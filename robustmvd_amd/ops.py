@@ -522,10 +522,11 @@ def pack_conv2d_weights(weight):
 
 
 @inference_only
-def conv2d_bn_relu(x, packed, Cin, Cout, ksize, stride, scale, shift, relu=True, out_layout=L.LAYOUT_NHWC, out=None):
+def conv2d_bn_relu(x, packed, Cin, Cout, ksize, stride, scale, shift, relu=True, out_layout=L.LAYOUT_NHWC, out=None, out_absmax=None):
     """K6. x: (B,3,H,W) image when Cin == 3, else channel-last (B,h,w,Cin).  Returns (B,ho,wo,Cout) for LAYOUT_NHWC,
     (B,Cout,ho,wo) for LAYOUT_NCHW, or the zero-bordered (B,ho+3,wo+3,Cout) staging map for LAYOUT_NHWC_BORDER
-    (`out` may pass a buffer whose border is already zero; only the interior is written)."""
+    (`out` may pass a buffer whose border is already zero; only the interior is written).  out_absmax: a zeroed one-element
+    device tensor that is raised to max |y| (mvd_conv2d_bn_relu_absmax_f32), for a split-operand layer behind this one."""
     lib = L.load()
     x = L.as_f32(x, "x")
     if Cin == 3:
@@ -556,6 +557,13 @@ def conv2d_bn_relu(x, packed, Cin, Cout, ksize, stride, scale, shift, relu=True,
         y = torch.zeros(oshape, dtype=torch.float32, device=dev)
     else:
         y = torch.empty(oshape, dtype=torch.float32, device=dev)
+    if out_absmax is not None:
+        yam = L.as_f32(out_absmax, "out_absmax", (1,), dev)
+        with torch.cuda.device(dev):
+            rc = lib.mvd_conv2d_bn_relu_absmax_f32(L.ptr(x), in_layout, L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), L.ptr(yam),
+                                                   out_layout, B, hi, wi, Cin, Cout, ksize, stride, int(bool(relu)), L.stream_of(x))
+        L.check(rc, "mvd_conv2d_bn_relu_absmax_f32")
+        return y
     with torch.cuda.device(dev):
         rc = lib.mvd_conv2d_bn_relu_f32(L.ptr(x), in_layout, L.ptr(packed), L.ptr(scale), L.ptr(shift), L.ptr(y), out_layout,
                                         B, hi, wi, Cin, Cout, ksize, stride, int(bool(relu)), L.stream_of(x))
