@@ -67,6 +67,7 @@ struct Tile2 {
 
 template <int CIN, int NT, int MT, int RPW, int KS, int ST, bool PLANAR>
 __global__ void __launch_bounds__(256) conv2d_kernel(Conv2dParams p) {
+    const float amax_seen = absmax_seen(p.absmax);  // read now, used by the epilogue
     using G = KGroup2<CIN>;
     using T = Tile2<CIN, NT, MT, RPW, KS, ST, PLANAR>;
     constexpr int TH = T::TH, TW = T::TW, ROWS = T::ROWS, COLS = T::COLS, PSTR = T::PSTR, PADK = KS / 2;
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(Conv2dParams p) {
     }
     if (p.absmax) {  // what a split-operand layer behind this one scales its activations by; a wave rarely has to raise the slot
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-        if ((threadIdx.x & 63) == 0) raise_absmax(p.absmax, amax);
+        if ((threadIdx.x & 63) == 0) raise_absmax_seen(p.absmax, amax, amax_seen);
     }
 }
 

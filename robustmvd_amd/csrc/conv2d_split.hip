@@ -223,6 +223,7 @@ __device__ __forceinline__ void c2_finish(const C2Params& p, size_t o, int cb, c
 
 template <int KH, int KW, int S, int U8, int WM, int NTW, bool NCHW3>
 __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
+    const float amax_seen = absmax_seen(p.part ? nullptr : p.yamax);  // read now, used by the epilogue
     using G = C2Geom<KH, KW, S, U8, NCHW3>;
     constexpr int WN = 4 / WM, MTW = 16 / WM, STEPS = G::STEPS, PB = G::PB, PLANE = G::PLANE;
     // (Measured and dropped: the next chunk's global reads sent to a per-thread LDS scratch by LDS-DMA under this chunk's MFMAs.
@@ -449,7 +450,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_split_kernel(C2Params p) {
         __syncthreads();
         if (tid == 0) {
             amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            raise_absmax(p.yamax, amax);
+            raise_absmax_seen(p.yamax, amax, amax_seen);
         }
     }
 }

@@ -117,6 +117,7 @@ struct TileGeom {
 // MODE: MVD_CONV3D_STRIDE1 / MVD_CONV3D_STRIDE2 / MVD_DECONV3D_STRIDE2 / MVD_CONV3D_S1_PAIR
 template <int CIN, int NT, int MT, int MODE>
 __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
+    const float amax_seen = absmax_seen(p.absmax);  // read now, used by the epilogue
     using G = KGroup<CIN>;
     using T = TileGeom<MODE, MT>;
     constexpr bool S2 = T::S2, DECONV = T::DECONV, PAIR = T::PAIR;
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(256) conv3d_kernel(ConvParams p) {
         __syncthreads();
         if (tid == 0) {
             amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            raise_absmax(p.absmax, amax);
+            raise_absmax_seen(p.absmax, amax, amax_seen);
         }
     }
 }
