@@ -19,11 +19,13 @@ int absmax_launch(const float* x, long long n, float* absmax, hipStream_t st);
 __device__ __forceinline__ void raise_absmax(float* slot, float m) {
     if (m > 0.f && m > __builtin_nontemporal_load(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
 }
-// The same with the slot read EARLY (at kernel start) by the caller: a short workgroup that read it at its end held its CU slot for
-// one more memory latency (K6's conv1: +20 us over 17,000 workgroups).  A stale `seen` only costs an atomic that changes nothing.
+// The same with a first check against a value of the slot read EARLY (at kernel start) by the caller: a short workgroup that reads the
+// slot at its end holds its CU slot for one more memory latency (K6's conv1: +20 us over 17,000 workgroups), and most workgroups
+// are below what the slot held when they started.  Only those above it look again (the early value alone is not enough: while the
+// maximum is still growing, every workgroup in flight would fire its atomic at the one address: conv1 413 instead of 140 us).
 __device__ __forceinline__ float absmax_seen(const float* slot) { return slot ? __builtin_nontemporal_load(slot) : 0.f; }
 __device__ __forceinline__ void raise_absmax_seen(float* slot, float m, float seen) {
-    if (m > 0.f && m > seen) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+    if (m > seen) raise_absmax(slot, m);
 }
 __device__ __forceinline__ float finite_abs_or_zero(float v) {
     const float a = fabsf(v);
