@@ -203,7 +203,7 @@ class FeatureNet(nn.Module):
         """split_layers (default on): conv2 .. conv6 and `feature` run on the split-operand implicit-GEMM kernel of the 2-D engine
         (ops.conv2d_split: fp32-grade, 1.2-1.5x the fp32 matrix instruction on these layers, tools/bench_featurenet_engine.py), the
         BN scale folded into their weights; conv0 and conv1 (full resolution, 3 / 8 input channels: traffic-bound) stay on the
-        fp32-MFMA kernel, conv1 leaving max |y| behind for conv2.  False: all eight layers on the fp32 matrix instruction."""
+        fp32-MFMA kernel.  False: all eight layers on the fp32 matrix instruction."""
         super().__init__()
         self.inplanes = 32
         self.split_layers = bool(split_layers)
@@ -249,20 +249,24 @@ class FeatureNet(nn.Module):
         slots = torch.zeros(8, dtype=torch.float32, device=x.device)  # max-|y| slots of the layers, raised by their producers
         for i in range(2):
             w, cin, cout, k, stride, scale, shift, relu = pk[i]
-            x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu, out_absmax=slots[0:1] if i == 1 else None)
+            x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu)
+        # max |conv1| by a pass of its own (29 us for 141 MB): as a by-product of conv1's store epilogue (out_absmax=) it cost 65 us in
+        # the frame, where the maximum grows across the image and many of the layer's 69,000 waves reach the atomic
+        a_in = ops.absmax(x)
         for j, (wts, relu) in enumerate(pk[8]):
             last = j == len(pk[8]) - 1
             if not last:
-                x = ops.conv2d_split(x, slots[j:j + 1], wts, act=2 if relu else 0, out_absmax=slots[j + 1:j + 2])
+                x = ops.conv2d_split(x, a_in, wts, act=2 if relu else 0, out_absmax=slots[j:j + 1])
+                a_in = slots[j:j + 1]
             elif out_layout == L.LAYOUT_NCHW:
-                x = ops.conv2d_split(x, slots[j:j + 1], wts, act=0, planar_out=True)
+                x = ops.conv2d_split(x, a_in, wts, act=0, planar_out=True)
             elif out_layout == L.LAYOUT_NHWC_BORDER:  # K3's zero-bordered staging map: the layer writes the interior
                 B, h, w_, _ = x.shape
                 buf = torch.zeros((B, h + 3, w_ + 3, wts.cout), dtype=torch.float32, device=x.device)
-                ops.conv2d_split(x, slots[j:j + 1], wts, act=0, out=buf[:, 1:h + 1, 1:w_ + 1, :])
+                ops.conv2d_split(x, a_in, wts, act=0, out=buf[:, 1:h + 1, 1:w_ + 1, :])
                 x = buf
             else:
-                x = ops.conv2d_split(x, slots[j:j + 1], wts, act=0)
+                x = ops.conv2d_split(x, a_in, wts, act=0)
         return x
 
     def forward(self, x):
