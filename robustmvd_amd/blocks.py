@@ -238,14 +238,15 @@ class FeatureNet(nn.Module):
         return pk
 
     @ops.inference_only
-    def forward_layout(self, x, out_layout):
-        """x (N,3,H,W) normalised images -> features at H/4 x W/4 in `out_layout` (L.LAYOUT_*)."""
+    def forward_layout(self, x, out_layout, return_absmax=False):
+        """x (N,3,H,W) normalised images -> features at H/4 x W/4 in `out_layout` (L.LAYOUT_*).  return_absmax: also max |feature|
+        over the batch as a one-element device tensor (a by-product of the last layer's store epilogue)."""
         pk = self._prepare()
         if not self.split_layers:
             for i, (w, cin, cout, k, stride, scale, shift, relu) in enumerate(pk):
                 x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu,
                                        out_layout=out_layout if i == len(pk) - 1 else L.LAYOUT_NHWC)
-            return x
+            return (x, ops.absmax(x)) if return_absmax else x
         slots = torch.zeros(8, dtype=torch.float32, device=x.device)  # max-|y| slots of the layers, raised by their producers
         for i in range(2):
             w, cin, cout, k, stride, scale, shift, relu = pk[i]
@@ -260,13 +261,17 @@ class FeatureNet(nn.Module):
                 a_in = slots[j:j + 1]
             elif out_layout == L.LAYOUT_NCHW:
                 x = ops.conv2d_split(x, a_in, wts, act=0, planar_out=True)
+                if return_absmax:
+                    slots[7:8] = ops.absmax(x)
             elif out_layout == L.LAYOUT_NHWC_BORDER:  # K3's zero-bordered staging map: the layer writes the interior
                 B, h, w_, _ = x.shape
                 buf = torch.zeros((B, h + 3, w_ + 3, wts.cout), dtype=torch.float32, device=x.device)
-                ops.conv2d_split(x, a_in, wts, act=0, out=buf[:, 1:h + 1, 1:w_ + 1, :])
+                ops.conv2d_split(x, a_in, wts, act=0, out=buf[:, 1:h + 1, 1:w_ + 1, :], out_absmax=slots[7:8])
                 x = buf
             else:
-                x = ops.conv2d_split(x, a_in, wts, act=0)
+                x = ops.conv2d_split(x, a_in, wts, act=0, out_absmax=slots[7:8])
+        if return_absmax:
+            return x, slots[7:8]
         return x
 
     def forward(self, x):

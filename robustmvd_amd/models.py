@@ -264,19 +264,24 @@ class MVSNet(nn.Module):
         projs = [select_by_index(proj, kidx)] + exclude_index(proj, kidx)
 
         # K6 x 8: ((V+1)*B, h+3, w+3, 32), the last layer writing straight into K3's zero-bordered staging layout
-        feats = self.feature.forward_layout(_as_batch(views), L.LAYOUT_NHWC_BORDER)
+        split = self.cost_regularization.conv0_split and not self.half_features
+        feats = self.feature.forward_layout(_as_batch(views), L.LAYOUT_NHWC_BORDER, return_absmax=split)
+        if split:
+            feats, a_feat = feats
         if self.half_features:
             feats = ops.to_f16(feats)  # one rounding to fp16 (zero border stays zero)
         feats = list(torch.split(feats, n, 0))
         amax = None
         if self.half_features:
             var = ops.warp_variance_f16(feats[0], feats[1:], projs[1:], projs[0], depth_samples)                          # K3 (fp16)
-        elif self.cost_regularization.conv0_split:  # the split first layer scales its activations by max |var|: a by-product of K3
-            var, amax = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True, staged=True,
-                                          exact_grid=self.exact_grid, return_absmax=True)                        # K3
         else:
             var = ops.warp_variance(feats[0], feats[1:], projs[1:], projs[0], depth_samples, channels_last=True, staged=True,
                                     exact_grid=self.exact_grid)                                                  # K3
+            if split:
+                # the range the split first layer scales by: a BOUND instead of K3's max |var| by-product (25 us in the frame).  A warped
+                # feature is a convex combination of features, and a variance is at most the mean square: var <= (max |feature|)^2;
+                # the bound is one or two orders loose, which moves conv0's absolute error floor from 2^-50 to about 2^-44 of max |var|
+                amax = a_feat * a_feat
         cost = self.cost_regularization.forward_channels_last(var, x_absmax=amax)                               # K4
         del var
         depth, conf = ops.softmax_regress(cost, depth_samples)                                                  # K5

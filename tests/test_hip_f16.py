@@ -268,7 +268,9 @@ def test_mvsnet_fp32_conv0_matches_default_model(dev):
     kw = dict(images=s["images"], poses=s["poses"], intrinsics=s["intrinsics"], keyview_idx=0, depth_range=(np.float32(0.5), np.float32(10.0)))
     p0, _ = m0.run(**kw)
     p1, _ = m1.run(**kw)
-    np.testing.assert_allclose(p1["depth"], p0["depth"], rtol=1e-5)
+    # two fp32-grade evaluations of the same network (FeatureNet's and the regulariser's stride-1 / stride-2 layers on the split-operand
+    # kernels against every layer on the fp32 matrix instruction): they differ by a few fp32 roundings of the regressed depth
+    np.testing.assert_allclose(p1["depth"], p0["depth"], rtol=3e-5)
 
 
 def test_conv0_f16_and_split_batch_of_two(dev):
