@@ -49,7 +49,18 @@ struct ConvParams {
     int Cout;
     int relu;
     int tiles_w, tiles_h;  // tiles over the (per-parity) output grid
+    int per_xcd;           // experiments (MVD_K4_XCD): > 0 = XCD k takes the k-th run of per_xcd consecutive tiles
 };
+
+// launch index -> tile index (workgroups go to the 8 XCDs round-robin)
+__device__ __forceinline__ int tile_index(const ConvParams& p) {
+    const int bx = blockIdx.x;
+    return (p.per_xcd > 0 && bx < 8 * p.per_xcd) ? (bx % 8) * p.per_xcd + bx / 8 : bx;
+}
+static int xcd_run(long long nblk, int bit) {
+    const char* e = exp_env("MVD_K4_XCD");
+    return (e && ((atoi(e) >> bit) & 1)) ? (int)(nblk / 8) : 0;
+}
 
 template <int CIN>
 struct KGroup {
@@ -1079,7 +1090,7 @@ __global__ void __launch_bounds__(256, 4) deconv3d_pair_kernel(ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int vox = lane & 15, q = lane >> 4;
-    int bx = blockIdx.x;
+    int bx = tile_index(p);
     const int tw = bx % p.tiles_w; bx /= p.tiles_w;
     const int th = bx % p.tiles_h; bx /= p.tiles_h;
     const int zd = bx % p.Di;
@@ -1242,6 +1253,7 @@ static int launch_deconv_pair(const ConvParams& p0, hipStream_t st) {
         set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
         return MVD_ERR_INVALID_ARG;
     }
+    p.per_xcd = xcd_run(nblk, 1);
     auto kern = deconv3d_pair_kernel<CIN, MT>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1290,7 +1302,7 @@ __global__ void __launch_bounds__(256, 4) conv3d_c8_to_1_kernel(ConvParams p) {
     constexpr int NEL = ROWS * COLS * 2, NPF = (NEL + 255) / 256, DZ = C8_DZ;
     __shared__ __attribute__((aligned(16))) float ring[3 * SLAB + 4];  // 37 KB + dummy slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bx = blockIdx.x;
+    int bx = tile_index(p);
     const int tw = bx % p.tiles_w; bx /= p.tiles_w;
     const int th = bx % p.tiles_h; bx /= p.tiles_h;
     const int nzc = (p.Do + DZ - 1) / DZ;
@@ -1424,6 +1436,7 @@ static int launch_c8_to_1(const ConvParams& p0, hipStream_t st) {
         set_error("conv3d: %lld workgroups exceed the grid limit", nblk);
         return MVD_ERR_INVALID_ARG;
     }
+    p.per_xcd = xcd_run(nblk, 0);
     hipLaunchKernelGGL(conv3d_c8_to_1_kernel, dim3((unsigned)nblk), dim3(256), 0, st, p);
     return launch_status("conv3d_c8_to_1");
 }
