@@ -17,9 +17,10 @@ __device__ __forceinline__ void atomic_add4(float* p, float4 v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K3 backward.  Thread = (pixel, channel quad); loops over the D planes.  Per plane: pass 1 gathers every view's sample
-// to form the mean, pass 2 gathers again per view (no per-view register array) and scatters 2 g (x_v - mean) / (V+1)
-// times the bilinear weights into that view's gradient map.  Sampling positions: the folded form of the forward kernel.
+// K3 backward.  Thread = (pixel, channel quad); loops over the D planes in chunks of 8.  Per chunk: pass 1 gathers every view's
+// samples to form the planes' means, pass 2 gathers again per view (no per-view register array) and scatters
+// 2 g (x_v - mean) / (V+1) times the bilinear weights into that view's gradient map, runs of planes that hit the same source
+// cell summed in registers first.  Sampling positions: the folded form of the forward kernel.
 struct WarpBwdParams {
     ViewPtrs src;            // V x (B,h+3,w+3,C) zero-bordered channel-last source features
     ViewOutPtrs gsrc;        // V x (B,h+3,w+3,C) zero-initialised gradient maps (border entries receive the padding's share)
@@ -76,29 +77,68 @@ __global__ void __launch_bounds__(256) warp_variance_backward_kernel(WarpBwdPara
                            fmaf(d.w, L.w11, fmaf(c.w, L.w01, fmaf(bq.w, L.w10, a.w * L.w00))));
     };
 
+    // Planes in chunks of BWD_DZ: the chunk's means stay in registers, then each view walks the chunk with ONE pending 2 x 2 cell of
+    // tap gradients in registers: consecutive planes of a pixel mostly sample the same source cell (the forward kernel's tap
+    // reuse), so the four taps' shares are summed in registers and go out as atomics only when the cell changes (and at the end
+    // of the chunk) — about 2.5x fewer atomics at the headline poses.
+    constexpr int DZ = 8;
+    const float c2 = 2.0f * inv_nv;
     float4 gk = make_float4(0, 0, 0, 0);
-    for (int d = 0; d < D; ++d) {
-        const float depth = p.depth[(size_t)b * D + d];
-        const float4 g = *reinterpret_cast<const float4*>(p.gvar + ((((size_t)b * D + d) * h + y) * w + x) * C + q * 4);
-        float4 sum = k;
-        for (int v = 0; v < V; ++v) {
-            const float4 xv = sample(p.src.p[v] + b * img, locate(v, depth));
-            sum.x += xv.x; sum.y += xv.y; sum.z += xv.z; sum.w += xv.w;
+    for (int d0 = 0; d0 < D; d0 += DZ) {
+        float4 mean[DZ], gs[DZ];  // gs = g * 2 / (V + 1)
+#pragma unroll
+        for (int dd = 0; dd < DZ; ++dd) {
+            mean[dd] = gs[dd] = make_float4(0, 0, 0, 0);
+            const int d = d0 + dd;
+            if (d >= D) continue;
+            const float depth = p.depth[(size_t)b * D + d];
+            const float4 g = *reinterpret_cast<const float4*>(p.gvar + ((((size_t)b * D + d) * h + y) * w + x) * C + q * 4);
+            float4 sum = k;
+            for (int v = 0; v < V; ++v) {
+                const float4 xv = sample(p.src.p[v] + b * img, locate(v, depth));
+                sum.x += xv.x; sum.y += xv.y; sum.z += xv.z; sum.w += xv.w;
+            }
+            mean[dd] = make_float4(sum.x * inv_nv, sum.y * inv_nv, sum.z * inv_nv, sum.w * inv_nv);
+            gs[dd] = make_float4(g.x * c2, g.y * c2, g.z * c2, g.w * c2);
+            gk.x += gs[dd].x * (k.x - mean[dd].x); gk.y += gs[dd].y * (k.y - mean[dd].y);
+            gk.z += gs[dd].z * (k.z - mean[dd].z); gk.w += gs[dd].w * (k.w - mean[dd].w);
         }
-        const float4 mean = make_float4(sum.x * inv_nv, sum.y * inv_nv, sum.z * inv_nv, sum.w * inv_nv);
-        const float c2 = 2.0f * inv_nv;
-        gk.x += g.x * c2 * (k.x - mean.x); gk.y += g.y * c2 * (k.y - mean.y);
-        gk.z += g.z * c2 * (k.z - mean.z); gk.w += g.w * c2 * (k.w - mean.w);
         for (int v = 0; v < V; ++v) {
-            const Loc L = locate(v, depth);
-            const float4 xv = sample(p.src.p[v] + b * img, L);
-            const float4 gx = make_float4(g.x * c2 * (xv.x - mean.x), g.y * c2 * (xv.y - mean.y), g.z * c2 * (xv.z - mean.z),
-                                          g.w * c2 * (xv.w - mean.w));
-            float* go = p.gsrc.p[v] + b * img + L.o;
-            atomic_add4(go, make_float4(gx.x * L.w00, gx.y * L.w00, gx.z * L.w00, gx.w * L.w00));
-            atomic_add4(go + C, make_float4(gx.x * L.w10, gx.y * L.w10, gx.z * L.w10, gx.w * L.w10));
-            atomic_add4(go + (size_t)W2 * C, make_float4(gx.x * L.w01, gx.y * L.w01, gx.z * L.w01, gx.w * L.w01));
-            atomic_add4(go + (size_t)W2 * C + C, make_float4(gx.x * L.w11, gx.y * L.w11, gx.z * L.w11, gx.w * L.w11));
+            const float* __restrict__ f = p.src.p[v] + b * img;
+            float* __restrict__ gv = p.gsrc.p[v] + b * img;
+            constexpr size_t NONE = ~(size_t)0;
+            size_t pend = NONE;
+            float4 t00 = make_float4(0, 0, 0, 0), t10 = t00, t01 = t00, t11 = t00;
+            auto flush = [&]() {
+                float* go = gv + pend;
+                atomic_add4(go, t00);
+                atomic_add4(go + C, t10);
+                atomic_add4(go + (size_t)W2 * C, t01);
+                atomic_add4(go + (size_t)W2 * C + C, t11);
+            };
+#pragma unroll
+            for (int dd = 0; dd < DZ; ++dd) {
+                const int d = d0 + dd;
+                if (d >= D) continue;
+                const Loc L = locate(v, p.depth[(size_t)b * D + d]);
+                const float4 xv = sample(f, L);
+                const float4 gx = make_float4(gs[dd].x * (xv.x - mean[dd].x), gs[dd].y * (xv.y - mean[dd].y),
+                                              gs[dd].z * (xv.z - mean[dd].z), gs[dd].w * (xv.w - mean[dd].w));
+                if (L.o != pend) {
+                    if (pend != NONE) flush();
+                    pend = L.o;
+                    t00 = make_float4(gx.x * L.w00, gx.y * L.w00, gx.z * L.w00, gx.w * L.w00);
+                    t10 = make_float4(gx.x * L.w10, gx.y * L.w10, gx.z * L.w10, gx.w * L.w10);
+                    t01 = make_float4(gx.x * L.w01, gx.y * L.w01, gx.z * L.w01, gx.w * L.w01);
+                    t11 = make_float4(gx.x * L.w11, gx.y * L.w11, gx.z * L.w11, gx.w * L.w11);
+                } else {
+                    t00.x = fmaf(gx.x, L.w00, t00.x); t00.y = fmaf(gx.y, L.w00, t00.y); t00.z = fmaf(gx.z, L.w00, t00.z); t00.w = fmaf(gx.w, L.w00, t00.w);
+                    t10.x = fmaf(gx.x, L.w10, t10.x); t10.y = fmaf(gx.y, L.w10, t10.y); t10.z = fmaf(gx.z, L.w10, t10.z); t10.w = fmaf(gx.w, L.w10, t10.w);
+                    t01.x = fmaf(gx.x, L.w01, t01.x); t01.y = fmaf(gx.y, L.w01, t01.y); t01.z = fmaf(gx.z, L.w01, t01.z); t01.w = fmaf(gx.w, L.w01, t01.w);
+                    t11.x = fmaf(gx.x, L.w11, t11.x); t11.y = fmaf(gx.y, L.w11, t11.y); t11.z = fmaf(gx.z, L.w11, t11.z); t11.w = fmaf(gx.w, L.w11, t11.w);
+                }
+            }
+            if (pend != NONE) flush();
         }
     }
     *reinterpret_cast<float4*>(p.gkey + b * img + self) = gk;
