@@ -32,6 +32,114 @@ struct ReduceParams {
     int B, C, D, h, w, V;
 };
 
+// One bilinear sample of 4 channels of source view v at the position plane `depth` puts key pixel (fx, fy) at.
+__device__ __forceinline__ float4 reduce_sample(const ReduceParams& p, int v, int b, float fx, float fy, float depth, int c0, int W2,
+                                                size_t img) {
+    const float xhi = (float)p.w, yhi = (float)p.h;
+    const int C = p.C;
+    const float* __restrict__ M = p.M.p[v] + (size_t)b * 12;
+    const float ax = fmaf(M[0], fx, fmaf(M[1], fy, M[2])), ay = fmaf(M[4], fx, fmaf(M[5], fy, M[6]));
+    const float az = fmaf(M[8], fx, fmaf(M[9], fy, M[10]));
+    const float X = fmaf(ax, depth, M[3]), Y = fmaf(ay, depth, M[7]), Z = fmaf(az, depth, M[11]);
+    float ix = fmaf(X / Z, p.scale_x, p.bias), iy = fmaf(Y / Z, p.scale_y, p.bias);
+    ix = __builtin_amdgcn_fmed3f(ix, -1.0f, xhi);  // NaN -> -1: all taps in the zero border
+    iy = __builtin_amdgcn_fmed3f(iy, -1.0f, yhi);
+    const float xf = floorf(ix), yf = floorf(iy);
+    const float wx = ix - xf, wy = iy - yf, ux = 1.0f - wx, uy = 1.0f - wy;
+    const float* __restrict__ f = p.src.p[v] + b * img + ((size_t)((int)yf + 1) * W2 + ((int)xf + 1)) * C + c0;
+    const float4 a = *reinterpret_cast<const float4*>(f), bq = *reinterpret_cast<const float4*>(f + C);
+    const float4 c = *reinterpret_cast<const float4*>(f + (size_t)W2 * C);
+    const float4 e = *reinterpret_cast<const float4*>(f + (size_t)W2 * C + C);
+    const float w00 = ux * uy, w10 = wx * uy, w01 = ux * wy, w11 = wx * wy;
+    return make_float4(fmaf(e.x, w11, fmaf(c.x, w01, fmaf(bq.x, w10, a.x * w00))),
+                       fmaf(e.y, w11, fmaf(c.y, w01, fmaf(bq.y, w10, a.y * w00))),
+                       fmaf(e.z, w11, fmaf(c.z, w01, fmaf(bq.z, w10, a.z * w00))),
+                       fmaf(e.w, w11, fmaf(c.w, w01, fmaf(bq.w, w10, a.w * w00))));
+}
+
+// The same reduction with the lanes of a pixel side by side (unit fastest: a pixel's units read whole 128-byte lines of a tap,
+// the plain kernel's lanes = pixels read 16 bytes of each) and the results of a plane turned through LDS, so that a channel's
+// 256 / units consecutive pixels leave as one run.  units = a power of two <= 64 (C / 4, or the number of groups).
+// grid (ceil(h w / ppw), B), ppw = 256 / units pixels per workgroup.  Same arithmetic as sweep_reduce_kernel, bit for bit.
+__global__ void __launch_bounds__(256) sweep_reduce_tile_kernel(ReduceParams p, int units) {
+    __shared__ __attribute__((aligned(16))) float tile[2][1024];
+    const int h = p.h, w = p.w, C = p.C, D = p.D, V = p.V;
+    const bool corr = p.mode == MVD_REDUCE_GROUPCORR;
+    const int qpu = corr ? C / p.groups / 4 : 1;
+    const int ppw = 256 / units;
+    const int tid = threadIdx.x, unit = tid % units, lp = tid / units;
+    const int b = blockIdx.y;
+    const long long npix = (long long)h * w, pix0 = (long long)blockIdx.x * ppw;
+    const long long pix = min(pix0 + lp, npix - 1);  // lanes beyond the map repeat its last pixel; their results are not stored
+    const int x = (int)(pix % w), y = (int)(pix / w);
+    const int W2 = w + 3;
+    const size_t img = (size_t)(h + 3) * W2 * C;
+    const float fx = (float)x + p.pix_offset, fy = (float)y + p.pix_offset;
+    const float inv_nv = 1.0f / (float)(V + 1);
+    const size_t dplane = (size_t)h * w;
+    const bool vec4 = (dplane % 4 == 0) && ppw >= 4 && ((size_t)p.out.p[0] & 15) == 0;
+    int buf = 0;
+
+    for (int d = 0; d < D; ++d) {
+        const float depth = p.depth_per_pixel ? p.depth[(((size_t)b * D + d) * h + y) * w + x] : p.depth[(size_t)b * D + d];
+        if (!corr) {
+            const int c0 = unit * 4;
+            const float4 k = *reinterpret_cast<const float4*>(p.key + b * img + ((size_t)(y + 1) * W2 + (x + 1)) * C + c0);
+            float4 s1, s2;
+            s2 = make_float4(k.x * k.x, k.y * k.y, k.z * k.z, k.w * k.w);
+            s1 = p.mode == MVD_REDUCE_VARIANCE_KEYSQ ? s2 : k;  // the reference's aliasing: both sums start from key^2
+            for (int v = 0; v < V; ++v) {
+                const float4 sv = reduce_sample(p, v, b, fx, fy, depth, c0, W2, img);
+                s1.x += sv.x; s1.y += sv.y; s1.z += sv.z; s1.w += sv.w;
+                s2.x = fmaf(sv.x, sv.x, s2.x); s2.y = fmaf(sv.y, sv.y, s2.y);
+                s2.z = fmaf(sv.z, sv.z, s2.z); s2.w = fmaf(sv.w, sv.w, s2.w);
+            }
+            const float mx = s1.x * inv_nv, my = s1.y * inv_nv, mz = s1.z * inv_nv, mw = s1.w * inv_nv;
+            float* t = tile[buf] + (c0 * ppw + lp);  // [channel][pixel]
+            t[0] = fmaf(s2.x, inv_nv, -mx * mx);
+            t[ppw] = fmaf(s2.y, inv_nv, -my * my);
+            t[2 * ppw] = fmaf(s2.z, inv_nv, -mz * mz);
+            t[3 * ppw] = fmaf(s2.w, inv_nv, -mw * mw);
+            __syncthreads();
+            // 1024 results = C channels x ppw pixels: thread -> 4 consecutive pixels of one channel
+            if (vec4) {
+                const int l4 = ppw / 4, ch = tid / l4, p4 = (tid % l4) * 4;
+                const long long po = pix0 + p4;
+                float* o = p.out.p[0] + (((size_t)b * C + ch) * D + d) * dplane + po;
+                const float4 r = *reinterpret_cast<const float4*>(tile[buf] + ch * ppw + p4);
+                if (po + 3 < npix) *reinterpret_cast<float4*>(o) = r;
+                else {
+                    if (po < npix) o[0] = r.x;
+                    if (po + 1 < npix) o[1] = r.y;
+                    if (po + 2 < npix) o[2] = r.z;
+                }
+            } else {
+                for (int e = tid; e < 1024; e += 256) {
+                    const int ch = e / ppw, pp = e % ppw;
+                    if (pix0 + pp < npix) p.out.p[0][(((size_t)b * C + ch) * D + d) * dplane + pix0 + pp] = tile[buf][e];
+                }
+            }
+            buf ^= 1;
+        } else {
+            for (int v = 0; v < V; ++v) {
+                float acc = 0.0f;
+                for (int qq = 0; qq < qpu; ++qq) {
+                    const int c0 = (unit * qpu + qq) * 4;
+                    const float4 k = *reinterpret_cast<const float4*>(p.key + b * img + ((size_t)(y + 1) * W2 + (x + 1)) * C + c0);
+                    const float4 sv = reduce_sample(p, v, b, fx, fy, depth, c0, W2, img);
+                    const float dot = fmaf(k.w, sv.w, fmaf(k.z, sv.z, fmaf(k.y, sv.y, k.x * sv.x)));
+                    acc = (qq == 0 ? 0.0f : acc) + dot;
+                }
+                tile[buf][unit * ppw + lp] = acc;  // [group][pixel]
+                __syncthreads();
+                const int g = tid / ppw, pp = tid % ppw;
+                if (pix0 + pp < npix) p.out.p[v][(((size_t)b * p.groups + g) * D + d) * dplane + pix0 + pp] = tile[buf][tid];
+                buf ^= 1;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) sweep_reduce_kernel(ReduceParams p) {
     const int h = p.h, w = p.w, C = p.C, D = p.D, V = p.V;
     const bool corr = p.mode == MVD_REDUCE_GROUPCORR;
@@ -157,6 +265,14 @@ int mvd_sweep_reduce_f32(const float* key_feat, const float* const* src_feat, co
     const int units = mode == MVD_REDUCE_GROUPCORR ? groups : C / 4;
     const long long nthr = (long long)B * units * h * w, nblk = (nthr + 255) / 256;
     MVD_REQUIRE(nblk <= 0x7fffffffLL, "sweep_reduce: grid too large");
+    // (experiments library, MVD_REDUCE_PLAIN: the pixel-per-lane kernel for every shape — the variants test compares the two)
+    if (units >= 2 && units <= 64 && (units & (units - 1)) == 0 && B <= 65535 && !exp_env("MVD_REDUCE_PLAIN")) {
+        const int ppw = 256 / units;
+        const long long nbx = ((long long)h * w + ppw - 1) / ppw;
+        MVD_REQUIRE(nbx <= 0x7fffffffLL, "sweep_reduce: grid too large");
+        hipLaunchKernelGGL(sweep_reduce_tile_kernel, dim3((unsigned)nbx, (unsigned)B), dim3(256), 0, st, p, units);
+        return launch_status("sweep_reduce_tile");
+    }
     hipLaunchKernelGGL(sweep_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, p);
     return launch_status("sweep_reduce");
 }

@@ -83,3 +83,33 @@ def test_group_correlation_wide_groups_vs_oracle(dev):
     with pytest.raises(ValueError):
         R.vis_cost_volumes(T(ref, dev), T(ref_cam, dev), [T(s, dev) for s in srcs], [T(c, dev) for c in srcs_cam], D, T(ds, dev),
                            T(di, dev), groups=16)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 12, 20, 5, 2, 8), (1, 32, 21, 37, 4, 3, 4), (1, 16, 9, 14, 3, 1, 2), (1, 64, 16, 32, 3, 2, 16)])
+def test_tiled_reduction_matches_plain_kernel(shape, dev, monkeypatch):
+    """the tiled kernel (a pixel's units side by side, stores turned through LDS) against the pixel-per-lane kernel of the
+    experiments library, bit for bit: vector and scalar store paths, ragged last workgroup, per-pixel and per-plane depths,
+    every reduction mode"""
+    import os
+    from robustmvd_amd import _lib as L, sweep_modes as SM
+    from test_hip_shapes import mvs_inputs
+    if not os.path.exists(L.EXP_LIB_PATH):
+        pytest.skip("the experiments library is not built (make -C robustmvd_amd/csrc exp)")
+    B, C, h, w, D, V, G = shape
+    feats, projs, key_inv, depth = mvs_inputs(B, C, h, w, D, V, seed=5)
+    ft = [T(f, dev) for f in feats]
+    Ms = [T((p @ key_inv)[:, :3, :4].astype(np.float32), dev) for p in projs]
+    dv = T(depth, dev)
+    dpp = (dv[:, :, None, None] * (1 + 0.01 * torch.rand(B, D, h, w, device=dev))).contiguous()
+    monkeypatch.setenv("MVD_REDUCE_PLAIN", "1")
+    cases = [(dv, L.REDUCE_VARIANCE, {}), (dpp, L.REDUCE_VARIANCE, {}), (dpp, L.REDUCE_VARIANCE_KEYSQ, {}),
+             (dv, L.REDUCE_GROUPCORR, dict(groups=G, pix_offset=0.5, stretch=False))]
+    for dep, mode, kw in cases:
+        got = SM.sweep_reduce(ft[0], ft[1:], Ms, dep, mode, **kw)  # product library: ignores the environment
+        with L.use_experiments_library():
+            ref = SM.sweep_reduce(ft[0], ft[1:], Ms, dep, mode, **kw)
+        got = got if isinstance(got, (list, tuple)) else [got]
+        ref = ref if isinstance(ref, (list, tuple)) else [ref]
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
