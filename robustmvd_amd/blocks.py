@@ -202,11 +202,12 @@ class FeatureNet(nn.Module):
     def __init__(self, split_layers=True):
         """split_layers (default on): conv2 .. conv6 and `feature` run on the split-operand implicit-GEMM kernel of the 2-D engine
         (ops.conv2d_split: fp32-grade, 1.2-1.5x the fp32 matrix instruction on these layers, tools/bench_featurenet_engine.py), the
-        BN scale folded into their weights; conv0 and conv1 (full resolution, 3 / 8 input channels: traffic-bound) stay on the
-        fp32-MFMA kernel.  False: all eight layers on the fp32 matrix instruction."""
+        BN scale folded into their weights; conv0 and conv1 (full resolution, 3 / 8 input channels: traffic-bound) run as ONE fp32
+        vector-ALU launch that keeps their intermediate in LDS (ops.conv2d_head).  False: all eight layers on the fp32 matrix instruction."""
         super().__init__()
         self.inplanes = 32
         self.split_layers = bool(split_layers)
+        self.fused_head = True  # with split_layers: conv0 and conv1 as one launch (False: two launches of the fp32-MFMA kernel)
         for i, s in enumerate(self.SPEC):
             setattr(self, f"conv{i}", ConvBnReLU(*s))
         self.feature = nn.Conv2d(32, 32, 3, 1, 1)
@@ -234,6 +235,9 @@ class FeatureNet(nn.Module):
                 _, _, _, _, stride, scale, shift, relu = pk[i]
                 sp.append((ops.pack_conv2d_weights_split(conv.weight.detach() * scale.view(-1, 1, 1, 1), shift, stride=stride), relu))
             pk.append(sp)
+            # conv0 -> conv1 in one launch (ops.conv2d_head): weights as [ky][kx][cin][cout]
+            hw = [getattr(self, f"conv{i}").conv.weight.detach().permute(2, 3, 1, 0).contiguous() for i in range(2)]
+            pk.append((hw[0], pk[0][5], pk[0][6], hw[1], pk[1][5], pk[1][6]))
         self._packed, self._packed_key = pk, key
         return pk
 
@@ -248,9 +252,12 @@ class FeatureNet(nn.Module):
                                        out_layout=out_layout if i == len(pk) - 1 else L.LAYOUT_NHWC)
             return (x, ops.absmax(x)) if return_absmax else x
         slots = torch.zeros(8, dtype=torch.float32, device=x.device)  # max-|y| slots of the layers, raised by their producers
-        for i in range(2):
-            w, cin, cout, k, stride, scale, shift, relu = pk[i]
-            x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu)
+        if self.fused_head:  # the 8-channel full-resolution intermediate never leaves the chip
+            x = ops.conv2d_head(x, *pk[9])
+        else:
+            for i in range(2):
+                w, cin, cout, k, stride, scale, shift, relu = pk[i]
+                x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu)
         # max |conv1| by a pass of its own (29 us for 141 MB): as a by-product of conv1's store epilogue (out_absmax=) it cost 65 us in
         # the frame, where the maximum grows across the image and many of the layer's 69,000 waves reach the atomic
         a_in = ops.absmax(x)

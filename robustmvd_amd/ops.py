@@ -522,6 +522,26 @@ def pack_conv2d_weights(weight):
 
 
 @inference_only
+def conv2d_head(image, w0, scale0, shift0, w1, scale1, shift1):
+    """FeatureNet's conv0 -> conv1 in one launch (mvd_conv2d_head_f32).  image (B,3,H,W); w0 (3,3,3,8), w1 (3,3,8,8): the Conv2d
+    weights as [ky][kx][cin][cout]; folded BN scale / shift (8) per layer.  Returns (B,H,W,8) channel-last."""
+    lib = L.load()
+    x = L.as_f32(image, "image")
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"image must be (B,3,H,W), got {tuple(x.shape)}")
+    B, _, H, W = x.shape
+    dev = x.device
+    w0 = L.as_f32(w0, "w0", (3, 3, 3, 8), dev)
+    w1 = L.as_f32(w1, "w1", (3, 3, 8, 8), dev)
+    vs = [L.as_f32(v, n, (8,), dev) for v, n in ((scale0, "scale0"), (shift0, "shift0"), (scale1, "scale1"), (shift1, "shift1"))]
+    y = torch.empty((B, H, W, 8), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mvd_conv2d_head_f32(L.ptr(x), L.ptr(w0), L.ptr(vs[0]), L.ptr(vs[1]), L.ptr(w1), L.ptr(vs[2]), L.ptr(vs[3]), L.ptr(y),
+                                     B, H, W, L.stream_of(x))
+    L.check(rc, "mvd_conv2d_head_f32")
+    return y
+
+
 def conv2d_bn_relu(x, packed, Cin, Cout, ksize, stride, scale, shift, relu=True, out_layout=L.LAYOUT_NHWC, out=None, out_absmax=None):
     """K6. x: (B,3,H,W) image when Cin == 3, else channel-last (B,h,w,Cin).  Returns (B,ho,wo,Cout) for LAYOUT_NHWC,
     (B,Cout,ho,wo) for LAYOUT_NCHW, or the zero-bordered (B,ho+3,wo+3,Cout) staging map for LAYOUT_NHWC_BORDER

@@ -238,3 +238,28 @@ def test_conv3d_split_absmax_by_product(dev):
         want = ops.conv3d_bn_relu_split(x, pk, sc, sh, relu=relu)
         got, amax = ops.conv3d_bn_relu_split(x, pk, sc, sh, relu=relu, return_absmax=True)
         assert torch.equal(got, want) and float(amax) == float(want.abs().max()) > 0
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 37, 75), (3, 8, 64), (1, 5, 3)])
+def test_conv2d_head_matches_float64_and_two_launches(shape, dev):
+    """FeatureNet's conv0 -> conv1 as one launch (mvd_conv2d_head_f32; mvsnet_components.py:47-48) against the float64
+    convolutions and against the two launches of the fp32-MFMA kernel: ragged tiles, images smaller than a tile, batch"""
+    import torch.nn.functional as F
+    from robustmvd_amd import ops
+    B, H, W = shape
+    g = torch.Generator(device="cpu").manual_seed(11)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w0, w1 = torch.randn(8, 3, 3, 3, generator=g) * 0.3, torch.randn(8, 8, 3, 3, generator=g) * 0.2
+    s0, b0, s1, b1 = (torch.randn(8, generator=g) for _ in range(4))
+    ref = F.relu(F.conv2d(img.double(), w0.double(), padding=1) * s0.double().view(1, -1, 1, 1) + b0.double().view(1, -1, 1, 1))
+    ref = F.relu(F.conv2d(ref, w1.double(), padding=1) * s1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1))
+    d = lambda t: t.to(dev)
+    got = ops.conv2d_head(d(img), d(w0.permute(2, 3, 1, 0).contiguous()), d(s0), d(b0), d(w1.permute(2, 3, 1, 0).contiguous()), d(s1), d(b1))
+    assert tuple(got.shape) == (B, H, W, 8)
+    want = ref.permute(0, 2, 3, 1)
+    scale = float(want.abs().max())
+    assert float((got.double().cpu() - want).abs().max()) <= 2e-6 * scale
+    p0, _, _, _ = ops.pack_conv2d_weights(d(w0))
+    p1, _, _, _ = ops.pack_conv2d_weights(d(w1))
+    two = ops.conv2d_bn_relu(ops.conv2d_bn_relu(d(img), p0, 3, 8, 3, 1, d(s0), d(b0)), p1, 8, 8, 3, 1, d(s1), d(b1))
+    assert float((got - two).abs().max()) <= 2e-6 * scale
