@@ -328,9 +328,14 @@ int mvd_conv2d_bn_relu_absmax_f32(const float* x, int in_layout, const float* pa
  *   rmvd/models/blocks/mvsnet_components.py:47-48 (ConvBnReLU(3,8,3,1,1), ConvBnReLU(8,8,3,1,1)), BN folded as above.
  *   image (B,3,H,W); w0 (3,3,3,8) and w1 (3,3,8,8): the Conv2d weights permuted to [ky][kx][cin][cout]; scale*, shift* (8);
  *   y (B,H,W,8) channel-last.  The 8-channel intermediate stays in LDS (the two launches write and read it once each).
- *   All pointers except image 16-byte aligned. */
+ *   All pointers except image 16-byte aligned.
+ *   tile_absmax (optional, mvd_conv2d_head_tile_count(B,H,W) floats): max |y| over the finite outputs of each workgroup's tile,
+ *   written with plain stores — mvd_absmax_f32 over that array is max |y| of the layer (what the split-operand layer behind it
+ *   scales by) at the cost of a 35 KB pass instead of one over y. */
+size_t mvd_conv2d_head_tile_count(int B, int H, int W);
 int mvd_conv2d_head_f32(const float* image, const float* w0, const float* scale0, const float* shift0, const float* w1,
-                        const float* scale1, const float* shift1, float* y, int B, int H, int W, mvd_stream_t stream);
+                        const float* scale1, const float* shift1, float* y, float* tile_absmax, int B, int H, int W,
+                        mvd_stream_t stream);
 
 /* K5 — replaces F.softmax + depth_regression + the 4-bin confidence of MVSNet.forward
  *   rmvd/models/mvsnet.py:139-160, rmvd/models/blocks/utils.py:271-274.

@@ -91,7 +91,8 @@ SIGNATURES = {
     "mvd_pack_conv2d_weights_f32": (_i, [_c_float_p, _i, _i, _i, _c_float_p, ctypes.c_void_p]),
     "mvd_conv2d_bn_relu_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _i] + [_i] * 8
                                + [ctypes.c_void_p]),
-    "mvd_conv2d_head_f32": (_i, [_c_float_p] * 8 + [_i] * 3 + [ctypes.c_void_p]),
+    "mvd_conv2d_head_tile_count": (_sz, [_i] * 3),
+    "mvd_conv2d_head_f32": (_i, [_c_float_p] * 9 + [_i] * 3 + [ctypes.c_void_p]),
     "mvd_conv2d_bn_relu_absmax_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _i] + [_i] * 8
                                       + [ctypes.c_void_p]),
     "mvd_softmax_regress_f32": (_i, [_c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),

@@ -252,15 +252,15 @@ class FeatureNet(nn.Module):
                                        out_layout=out_layout if i == len(pk) - 1 else L.LAYOUT_NHWC)
             return (x, ops.absmax(x)) if return_absmax else x
         slots = torch.zeros(8, dtype=torch.float32, device=x.device)  # max-|y| slots of the layers, raised by their producers
-        if self.fused_head:  # the 8-channel full-resolution intermediate never leaves the chip
-            x = ops.conv2d_head(x, *pk[9])
+        if self.fused_head:  # the 8-channel full-resolution intermediate never leaves the chip; max |conv1| from per-tile maxima
+            x, a_in = ops.conv2d_head(x, *pk[9], return_absmax=True)
         else:
             for i in range(2):
                 w, cin, cout, k, stride, scale, shift, relu = pk[i]
                 x = ops.conv2d_bn_relu(x, w, cin, cout, k, stride, scale, shift, relu=relu)
-        # max |conv1| by a pass of its own (29 us for 141 MB): as a by-product of conv1's store epilogue (out_absmax=) it cost 65 us in
-        # the frame, where the maximum grows across the image and many of the layer's 69,000 waves reach the atomic
-        a_in = ops.absmax(x)
+            # max |conv1| by a pass of its own (29 us for 141 MB): as a by-product of conv1's store epilogue (out_absmax=) it cost 65 us
+            # in the frame, where the maximum grows across the image and many of the layer's 69,000 waves reach the atomic
+            a_in = ops.absmax(x)
         for j, (wts, relu) in enumerate(pk[8]):
             last = j == len(pk[8]) - 1
             if not last:

@@ -30,6 +30,7 @@ struct HeadParams {
     const float* s1;
     const float* b1;
     float* y;          // (B,H,W,8)
+    float* tile_max;   // optional: one float per workgroup, max |y| over the finite outputs of its tile
     int B, H, W, tiles_x, tiles_y;
 };
 
@@ -121,32 +122,50 @@ __global__ void __launch_bounds__(256) conv2d_head_kernel(HeadParams p) {
     const hd4 sa = sp[0], sb = sp[1], ba = bp[0], bb = bp[1];
     const hd4 zero = {0.f, 0.f, 0.f, 0.f};
     const int gc = c0 + col;
-    if (gc >= W) return;
+    float m = 0.0f;
     auto store = [&](const hd2 (&a)[4], int gr) {
-        if (gr >= H) return;
+        if (gr >= H || gc >= W) return;
         hd4 va = {fmaf(a[0].x, sa.x, ba.x), fmaf(a[0].y, sa.y, ba.y), fmaf(a[1].x, sa.z, ba.z), fmaf(a[1].y, sa.w, ba.w)};
         hd4 vb = {fmaf(a[2].x, sb.x, bb.x), fmaf(a[2].y, sb.y, bb.y), fmaf(a[3].x, sb.z, bb.z), fmaf(a[3].y, sb.w, bb.w)};
+        va = __builtin_elementwise_max(va, zero);
+        vb = __builtin_elementwise_max(vb, zero);
         hd4* o = reinterpret_cast<hd4*>(p.y + (((size_t)b * H + gr) * W + gc) * 8);
-        o[0] = __builtin_elementwise_max(va, zero);
-        o[1] = __builtin_elementwise_max(vb, zero);
+        o[0] = va;
+        o[1] = vb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaxf(finite_abs_or_zero(va[k]), finite_abs_or_zero(vb[k])));
     };
     store(accA, r0 + row);
     store(accB, r0 + row + 4);
+    if (p.tile_max) {  // per-tile maxima with plain stores (a second tiny pass reduces them): no atomics on one address
+        __shared__ float wmax[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) wmax[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) p.tile_max[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    }
 }
 
 }  // namespace mvd
 
 extern "C" {
 
+size_t mvd_conv2d_head_tile_count(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)((W + mvd::HD_TW - 1) / mvd::HD_TW) * ((H + mvd::HD_TH - 1) / mvd::HD_TH) * B;
+}
+
 int mvd_conv2d_head_f32(const float* image, const float* w0, const float* scale0, const float* shift0, const float* w1,
-                        const float* scale1, const float* shift1, float* y, int B, int H, int W, mvd_stream_t stream) {
+                        const float* scale1, const float* shift1, float* y, float* tile_absmax, int B, int H, int W,
+                        mvd_stream_t stream) {
     using namespace mvd;
     MVD_REQUIRE(image && w0 && scale0 && shift0 && w1 && scale1 && shift1 && y, "conv2d_head: NULL argument");
     MVD_REQUIRE(B > 0 && H > 0 && W > 0, "conv2d_head: non-positive dimension");
     MVD_REQUIRE((((uintptr_t)w0 | (uintptr_t)w1 | (uintptr_t)scale0 | (uintptr_t)shift0 | (uintptr_t)scale1 | (uintptr_t)shift1 | (uintptr_t)y) & 15) == 0,
                 "conv2d_head: weights, scales, shifts and y must be 16-byte aligned");
     HeadParams p{};
-    p.img = image; p.w0 = w0; p.s0 = scale0; p.b0 = shift0; p.w1 = w1; p.s1 = scale1; p.b1 = shift1; p.y = y;
+    p.img = image; p.w0 = w0; p.s0 = scale0; p.b0 = shift0; p.w1 = w1; p.s1 = scale1; p.b1 = shift1; p.y = y; p.tile_max = tile_absmax;
     p.B = B; p.H = H; p.W = W;
     p.tiles_x = (W + HD_TW - 1) / HD_TW;
     p.tiles_y = (H + HD_TH - 1) / HD_TH;

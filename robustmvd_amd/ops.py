@@ -522,9 +522,10 @@ def pack_conv2d_weights(weight):
 
 
 @inference_only
-def conv2d_head(image, w0, scale0, shift0, w1, scale1, shift1):
+def conv2d_head(image, w0, scale0, shift0, w1, scale1, shift1, return_absmax=False):
     """FeatureNet's conv0 -> conv1 in one launch (mvd_conv2d_head_f32).  image (B,3,H,W); w0 (3,3,3,8), w1 (3,3,8,8): the Conv2d
-    weights as [ky][kx][cin][cout]; folded BN scale / shift (8) per layer.  Returns (B,H,W,8) channel-last."""
+    weights as [ky][kx][cin][cout]; folded BN scale / shift (8) per layer.  Returns (B,H,W,8) channel-last; with return_absmax also
+    max |y| as a one-element device tensor (per-tile maxima from the kernel, reduced by a pass over that small array)."""
     lib = L.load()
     x = L.as_f32(image, "image")
     if x.dim() != 4 or x.shape[1] != 3:
@@ -535,11 +536,12 @@ def conv2d_head(image, w0, scale0, shift0, w1, scale1, shift1):
     w1 = L.as_f32(w1, "w1", (3, 3, 8, 8), dev)
     vs = [L.as_f32(v, n, (8,), dev) for v, n in ((scale0, "scale0"), (shift0, "shift0"), (scale1, "scale1"), (shift1, "shift1"))]
     y = torch.empty((B, H, W, 8), dtype=torch.float32, device=dev)
+    tiles = torch.empty(lib.mvd_conv2d_head_tile_count(B, H, W), dtype=torch.float32, device=dev) if return_absmax else None
     with torch.cuda.device(dev):
         rc = lib.mvd_conv2d_head_f32(L.ptr(x), L.ptr(w0), L.ptr(vs[0]), L.ptr(vs[1]), L.ptr(w1), L.ptr(vs[2]), L.ptr(vs[3]), L.ptr(y),
-                                     B, H, W, L.stream_of(x))
+                                     L.ptr(tiles), B, H, W, L.stream_of(x))
     L.check(rc, "mvd_conv2d_head_f32")
-    return y
+    return (y, absmax(tiles)) if return_absmax else y
 
 
 def conv2d_bn_relu(x, packed, Cin, Cout, ksize, stride, scale, shift, relu=True, out_layout=L.LAYOUT_NHWC, out=None, out_absmax=None):

@@ -254,8 +254,11 @@ def test_conv2d_head_matches_float64_and_two_launches(shape, dev):
     ref = F.relu(F.conv2d(img.double(), w0.double(), padding=1) * s0.double().view(1, -1, 1, 1) + b0.double().view(1, -1, 1, 1))
     ref = F.relu(F.conv2d(ref, w1.double(), padding=1) * s1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1))
     d = lambda t: t.to(dev)
-    got = ops.conv2d_head(d(img), d(w0.permute(2, 3, 1, 0).contiguous()), d(s0), d(b0), d(w1.permute(2, 3, 1, 0).contiguous()), d(s1), d(b1))
+    args = (d(img), d(w0.permute(2, 3, 1, 0).contiguous()), d(s0), d(b0), d(w1.permute(2, 3, 1, 0).contiguous()), d(s1), d(b1))
+    got = ops.conv2d_head(*args)
     assert tuple(got.shape) == (B, H, W, 8)
+    got2, amax = ops.conv2d_head(*args, return_absmax=True)  # per-tile maxima, reduced: exactly max |y|
+    assert torch.equal(got2, got) and float(amax) == float(got.abs().max())
     want = ref.permute(0, 2, 3, 1)
     scale = float(want.abs().max())
     assert float((got.double().cpu() - want).abs().max()) <= 2e-6 * scale
